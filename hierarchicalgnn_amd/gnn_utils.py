@@ -1,0 +1,137 @@
+"""Drop-in message-passing cells: same class names, constructor (`hparams` dict),
+sub-module names (hence ``state_dict`` keys) and ``forward`` signatures as the
+reference's Modules/gnn_utils.py, evaluated by the MI355X HIP kernels.
+
+    InteractionGNNCell      <- Modules/gnn_utils.py:17-71
+    HierarchicalGNNCell     <- Modules/gnn_utils.py:73-169
+
+Differences that are deliberate (and invisible through the interface):
+  * the scatter_add aggregations are an atomics-free destination-sorted
+    segmented reduce over a per-event GraphPlan (bitwise reproducible);
+  * ``w * X[g]`` products ([B, L], 614 MB at L=256) are never materialised:
+    K2/K3 run as one fused gather-scale-reduce kernel;
+  * gathers feeding the edge MLP run as whole-row HIP gathers whose backward is
+    the same segmented reduce (no atomics in backward either).
+Like the reference, each update runs under ``torch.utils.checkpoint`` when
+gradients are being recorded (gnn_utils.py:14-15); pass
+``hparams["checkpointing"] = False`` to keep activations instead.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch.utils.checkpoint import checkpoint
+
+from .mlp import concat_mlp
+from .ops import gather_scale_scatter, scatter_add
+from .utils import make_mlp
+
+
+def _maybe_checkpoint(enabled, fn, *args):
+    if enabled and torch.is_grad_enabled() and any(torch.is_tensor(a) and a.requires_grad for a in args):
+        return checkpoint(fn, *args, use_reentrant=True)
+    return fn(*args)
+
+
+class InteractionGNNCell(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        L, H = hparams["latent"], hparams["hidden"]
+        act = hparams["hidden_activation"]
+        # edge network: 3L -> H -> L, Tanh output          (gnn_utils.py:22-30)
+        self.edge_network = make_mlp(3 * L, H, L, hparams["nb_edge_layer"], layer_norm=hparams["layernorm"],
+                                     output_activation="Tanh", hidden_activation=act)
+        # node network: 2L -> H -> H -> L                   (gnn_utils.py:33-41)
+        self.node_network = make_mlp(2 * L, H, L, hparams["nb_node_layer"], layer_norm=hparams["layernorm"],
+                                     output_activation=act, hidden_activation=act)
+        self.hparams = hparams
+        self._ckpt = bool(hparams.get("checkpointing", True))
+
+    # gnn_utils.py:46-54
+    def _node_update(self, nodes, edges, graph):
+        edge_messages = scatter_add(edges, graph[1], dim=0, dim_size=nodes.shape[0])
+        return concat_mlp(self.node_network, [(nodes, None), (edge_messages, None)], skip=nodes)
+
+    # gnn_utils.py:57-64
+    def _edge_update(self, nodes, edges, graph):
+        return concat_mlp(self.edge_network, [(nodes, graph[0]), (nodes, graph[1]), (edges, None)], skip=edges)
+
+    def node_update(self, nodes, edges, graph):
+        return _maybe_checkpoint(self._ckpt, self._node_update, nodes, edges, graph)
+
+    def edge_update(self, nodes, edges, graph):
+        return _maybe_checkpoint(self._ckpt, self._edge_update, nodes, edges, graph)
+
+    # gnn_utils.py:66-71 -- the edge update sees the UPDATED nodes
+    def forward(self, nodes, edges, graph):
+        nodes = self.node_update(nodes, edges, graph)
+        edges = self.edge_update(nodes, edges, graph)
+        return nodes, edges
+
+
+class HierarchicalGNNCell(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        L, H = hparams["latent"], hparams["hidden"]
+        act = hparams["hidden_activation"]
+        ln = hparams["layernorm"]
+        ne, nn_ = hparams["nb_edge_layer"], hparams["nb_node_layer"]
+        # gnn_utils.py:77-115
+        self.edge_network = make_mlp(3 * L, H, L, ne, layer_norm=ln, output_activation="Tanh", hidden_activation=act)
+        self.node_network = make_mlp(3 * L, H, L, nn_, layer_norm=ln, output_activation=act, hidden_activation=act)
+        self.supernode_network = make_mlp(3 * L, H, L, nn_, layer_norm=ln, output_activation=act,
+                                          hidden_activation=act)
+        self.superedge_network = make_mlp(3 * L, H, L, ne, layer_norm=ln, output_activation="Tanh",
+                                          hidden_activation=act)
+        self.hparams = hparams
+        self._ckpt = bool(hparams.get("checkpointing", True))
+
+    # gnn_utils.py:120-127  (K2 + K1)
+    def _node_update(self, nodes, edges, supernodes, graph, bipartite_graph, bipartite_edge_weights):
+        supernode_messages = gather_scale_scatter(supernodes, bipartite_graph[1], bipartite_graph[0],
+                                                  nodes.shape[0], bipartite_edge_weights)
+        edge_messages = scatter_add(edges, graph[1], dim=0, dim_size=nodes.shape[0])
+        return concat_mlp(self.node_network, [(nodes, None), (edge_messages, None), (supernode_messages, None)],
+                          skip=nodes)
+
+    # gnn_utils.py:130-135
+    def _edge_update(self, nodes, edges, graph):
+        return concat_mlp(self.edge_network, [(nodes, graph[0]), (nodes, graph[1]), (edges, None)], skip=edges)
+
+    # gnn_utils.py:138-145  (K3 + K4)
+    def _supernode_update(self, nodes, supernodes, superedges, bipartite_graph, bipartite_edge_weights,
+                          super_graph, super_edge_weights):
+        node_messages = gather_scale_scatter(nodes, bipartite_graph[0], bipartite_graph[1],
+                                             supernodes.shape[0], bipartite_edge_weights)
+        attention_messages = scatter_add(superedges, super_graph[1], dim=0, dim_size=supernodes.shape[0],
+                                         weight=super_edge_weights)
+        return concat_mlp(self.supernode_network,
+                          [(supernodes, None), (attention_messages, None), (node_messages, None)], skip=supernodes)
+
+    # gnn_utils.py:148-153
+    def _superedge_update(self, supernodes, superedges, super_graph, super_edge_weights):
+        return concat_mlp(self.superedge_network,
+                          [(supernodes, super_graph[0]), (supernodes, super_graph[1]), (superedges, None)],
+                          skip=superedges)
+
+    def node_update(self, *a):
+        return _maybe_checkpoint(self._ckpt, self._node_update, *a)
+
+    def edge_update(self, *a):
+        return _maybe_checkpoint(self._ckpt, self._edge_update, *a)
+
+    def supernode_update(self, *a):
+        return _maybe_checkpoint(self._ckpt, self._supernode_update, *a)
+
+    def superedge_update(self, *a):
+        return _maybe_checkpoint(self._ckpt, self._superedge_update, *a)
+
+    # gnn_utils.py:155-169 : supernode -> node -> superedge -> edge
+    def forward(self, nodes, edges, supernodes, superedges, graph, bipartite_graph, bipartite_edge_weights,
+                super_graph, super_edge_weights):
+        supernodes = self.supernode_update(nodes, supernodes, superedges, bipartite_graph,
+                                           bipartite_edge_weights, super_graph, super_edge_weights)
+        nodes = self.node_update(nodes, edges, supernodes, graph, bipartite_graph, bipartite_edge_weights)
+        superedges = self.superedge_update(supernodes, superedges, super_graph, super_edge_weights)
+        edges = self.edge_update(nodes, edges, graph)
+        return nodes, edges, supernodes, superedges

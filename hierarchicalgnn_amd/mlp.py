@@ -1,0 +1,34 @@
+"""``concat -> make_mlp Sequential -> (+skip)`` evaluation for the cells.
+
+Every MLP on the hot path has the shape  out = MLP(cat[seg_0, seg_1, seg_2]) + skip
+where each segment is either a tensor or a row gather ``table[index]``
+(Modules/gnn_utils.py:52-53, :61-62, :124-126, :134, :142-144, :152).
+
+``concat_mlp`` is the single entry point the cells use.  Gathers run in the HIP
+row-gather kernel (backward: atomics-free segmented reduce).  The dense layers
+are evaluated by the fused fp32-MFMA kernel when the shape is supported
+(``fused.py``), otherwise by the library GEMM path (rocBLAS through ATen) --
+both on the GPU; neither is a CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .ops import gather_rows
+
+Segment = Tuple[torch.Tensor, Optional[torch.Tensor]]  # (table, index or None)
+
+
+def concat_mlp(net: nn.Sequential, segments: Sequence[Segment], skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+    from . import fused
+    if fused.supported(net, segments, skip):
+        return fused.fused_concat_mlp(net, segments, skip)
+    parts: List[torch.Tensor] = []
+    for table, index in segments:
+        parts.append(table if index is None else gather_rows(table, index))
+    x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
+    y = net(x)
+    return y if skip is None else y + skip

@@ -1,0 +1,237 @@
+"""Operator-level drop-ins backed by libhgnn_hip.so.
+
+``scatter_add(src, index, dim=0, dim_size=N)`` keeps torch_scatter's calling
+convention exactly as the reference uses it (Modules/gnn_utils.py:50,124,125,
+142,143; BipartiteClassification/Models/HGNN_GMM.py:269).  The fused forms
+(``gather_scale_scatter``) compute ``scatter_add(w * X[g], d, dim_size)``
+without materialising the ``[B, L]`` product the reference builds first.
+
+All functions are ``torch.autograd.Function``s with hand-written HIP backward
+kernels; they hold no per-call state and are safe under reentrant
+``torch.utils.checkpoint`` recompute (gnn_utils.py:14-15).  fp32, HIP device
+tensors only: anything else raises (there is no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .plan import GraphPlan, get_plan
+
+
+def _require_hip(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"hierarchicalgnn_amd: `{name}` must be a HIP device tensor "
+                           "(no CPU fallback; build + run on an MI355X)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"hierarchicalgnn_amd: `{name}` must be float32, got {t.dtype}")
+
+
+def _seg_reduce(plan: GraphPlan, src2d: torch.Tensor, weight: Optional[torch.Tensor],
+                row_scale: Optional[torch.Tensor]) -> torch.Tensor:
+    F = int(src2d.shape[1])
+    out = torch.empty((plan.N, F), dtype=torch.float32, device=src2d.device)
+    if plan.N == 0 or F == 0:
+        return out
+    lib = _lib.load()
+    with torch.cuda.device(src2d.device):
+        _lib.check(lib.hgnn_segment_reduce_f32(
+            ctypes.byref(plan.c), _lib.ptr(src2d), F, _lib.ptr(weight), _lib.ptr(row_scale),
+            _lib.ptr(out), _lib.ptr(plan.partial(F)), _lib.current_stream(src2d.device)),
+            "hgnn_segment_reduce_f32")
+    return out
+
+
+def _gather_rows(table: torch.Tensor, idx32: torch.Tensor, M: int, weight: Optional[torch.Tensor] = None,
+                 row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    F = int(table.shape[1])
+    out = torch.empty((M, F), dtype=torch.float32, device=table.device)
+    if M == 0 or F == 0:
+        return out
+    lib = _lib.load()
+    with torch.cuda.device(table.device):
+        _lib.check(lib.hgnn_gather_rows_f32(
+            _lib.ptr(table), int(table.shape[0]), F, _lib.ptr(idx32), M, _lib.ptr(weight),
+            _lib.ptr(row_scale), _lib.ptr(out), _lib.current_stream(table.device)),
+            "hgnn_gather_rows_f32")
+    return out
+
+
+def _edge_dot(A: torch.Tensor, ai: Optional[torch.Tensor], B: torch.Tensor, bi: Optional[torch.Tensor],
+              M: int) -> torch.Tensor:
+    F = int(A.shape[1])
+    out = torch.empty((M,), dtype=torch.float32, device=A.device)
+    if M == 0:
+        return out
+    lib = _lib.load()
+    with torch.cuda.device(A.device):
+        _lib.check(lib.hgnn_edge_dot_f32(
+            _lib.ptr(A), _lib.ptr(ai), int(A.shape[0]), _lib.ptr(B), _lib.ptr(bi), int(B.shape[0]),
+            F, M, _lib.ptr(out), _lib.current_stream(A.device)), "hgnn_edge_dot_f32")
+    return out
+
+
+# --------------------------------------------------------------------------- K1 / K4
+class _ScatterAdd(torch.autograd.Function):
+    """out[d] = sum_{e: index[e]=d} (w[e] *) src[e]"""
+
+    @staticmethod
+    def forward(ctx, src, weight, plan: GraphPlan):
+        src_c = src.contiguous()
+        w_c = weight.contiguous().view(-1) if weight is not None else None
+        ctx.plan = plan
+        ctx.has_w = weight is not None
+        ctx.w_shape = weight.shape if weight is not None else None
+        if ctx.has_w:
+            ctx.save_for_backward(src_c, w_c)
+        return _seg_reduce(plan, src_c, w_c, None)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan = ctx.plan
+        g = grad_out.contiguous()
+        grad_src = grad_w = None
+        if ctx.has_w:
+            src_c, w_c = ctx.saved_tensors
+            if ctx.needs_input_grad[0]:
+                grad_src = _gather_rows(g, plan.dst32, plan.M, weight=w_c)
+            if ctx.needs_input_grad[1]:
+                grad_w = _edge_dot(src_c, None, g, plan.dst32, plan.M).view(ctx.w_shape)
+        elif ctx.needs_input_grad[0]:
+            grad_src = _gather_rows(g, plan.dst32, plan.M)
+        return grad_src, grad_w, None
+
+
+def scatter_add(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size: Optional[int] = None,
+                out=None, plan: Optional[GraphPlan] = None, weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch_scatter.scatter_add for the call shape the reference uses.
+
+    src   Tensor[M, ...] float32; index LongTensor[M] (broadcast along features); dim must be 0.
+    Returns a freshly allocated Tensor[dim_size, ...] with zero rows for absent
+    destinations.  Differentiable w.r.t. ``src`` (and ``weight``).
+    ``weight`` (Tensor[M] or [M,1]) is an extension: fused ``scatter_add(src*weight, ...)``
+    as at Modules/gnn_utils.py:143.
+    """
+    if dim != 0 and dim != -src.dim():
+        raise RuntimeError("hierarchicalgnn_amd.scatter_add: only dim=0 is implemented (the reference's use)")
+    if out is not None:
+        raise RuntimeError("hierarchicalgnn_amd.scatter_add: `out=` is not supported")
+    _require_hip(src, "src")
+    if index.dim() != 1 or index.shape[0] != src.shape[0]:
+        raise RuntimeError("hierarchicalgnn_amd.scatter_add: index must be 1-D with one entry per row of src")
+    if index.device != src.device:
+        raise RuntimeError("hierarchicalgnn_amd.scatter_add: index and src are on different devices")
+    if dim_size is None:
+        dim_size = int(index.max().item()) + 1 if index.numel() else 0
+    dim_size = int(dim_size)
+    if plan is None:
+        plan = get_plan(index, dim_size)
+    elif plan.M != index.numel() or plan.N != dim_size or plan.c.has_gather:
+        raise RuntimeError("hierarchicalgnn_amd.scatter_add: plan does not match index/dim_size")
+    trailing = tuple(src.shape[1:])
+    src2d = src.reshape(src.shape[0], -1)
+    if weight is not None:
+        _require_hip(weight, "weight")
+        if weight.numel() != src.shape[0]:
+            raise RuntimeError("hierarchicalgnn_amd.scatter_add: weight must have one entry per row")
+    res = _ScatterAdd.apply(src2d, weight, plan)
+    return res.reshape((dim_size,) + trailing)
+
+
+# --------------------------------------------------------------------------- K2 / K3 / K5
+class _GatherScaleScatter(torch.autograd.Function):
+    """out[d] = sum_{b: dst[b]=d} w[b] * rs[g[b]] * X[g[b]]"""
+
+    @staticmethod
+    def forward(ctx, X, weight, row_scale, plan_fwd: GraphPlan, plan_bwd: GraphPlan):
+        X_c = X.contiguous()
+        w_c = weight.contiguous().view(-1)
+        rs_c = row_scale.contiguous().view(-1) if row_scale is not None else None
+        ctx.plan_fwd, ctx.plan_bwd = plan_fwd, plan_bwd
+        ctx.w_shape = weight.shape
+        ctx.rs_shape = row_scale.shape if row_scale is not None else None
+        ctx.save_for_backward(X_c, w_c, rs_c)
+        return _seg_reduce(plan_fwd, X_c, w_c, rs_c)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        X_c, w_c, rs_c = ctx.saved_tensors
+        pf, pb = ctx.plan_fwd, ctx.plan_bwd
+        g = grad_out.contiguous()
+        grad_X = grad_w = grad_rs = None
+        if ctx.needs_input_grad[0] or (rs_c is not None and ctx.needs_input_grad[2]):
+            # T[s] = sum_{b: g[b]=s} w[b] * grad_out[dst[b]]   (transposed plan)
+            T = _seg_reduce(pb, g, w_c, None)
+            if rs_c is not None:
+                if ctx.needs_input_grad[2]:
+                    grad_rs = (T * X_c).sum(dim=1).view(ctx.rs_shape)
+                if ctx.needs_input_grad[0]:
+                    grad_X = T * rs_c.unsqueeze(1)
+            else:
+                grad_X = T
+        if ctx.needs_input_grad[1]:
+            # dw[b] = rs[g[b]] * <grad_out[dst[b]], X[g[b]]>
+            d = _edge_dot(g, pf.dst32, X_c, pb.dst32, pf.M)
+            if rs_c is not None:
+                d = d * rs_c[pb.dst32.long()[:pf.M]] if pf.M else d
+            grad_w = d.view(ctx.w_shape)
+        return grad_X, grad_w, grad_rs, None, None
+
+
+def gather_scale_scatter(X: torch.Tensor, gather_index: torch.Tensor, dst_index: torch.Tensor, dim_size: int,
+                         weight: torch.Tensor, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused ``scatter_add(weight * (row_scale[:,None] * X)[gather_index], dst_index, dim=0, dim_size)``.
+
+    K2: Modules/gnn_utils.py:124  (X=supernodes, gather=bipartite_graph[1], dst=bipartite_graph[0])
+    K3: Modules/gnn_utils.py:142  (X=nodes,      gather=bipartite_graph[0], dst=bipartite_graph[1])
+    K5: BipartiteClassification/Models/HGNN_GMM.py:269 (K3 with row_scale = 1/||nodes||_1)
+    The [B, L] product is never written to HBM.  Differentiable w.r.t. X, weight, row_scale.
+    """
+    _require_hip(X, "X")
+    _require_hip(weight, "weight")
+    if X.dim() != 2:
+        raise RuntimeError("gather_scale_scatter: X must be [rows, features]")
+    if weight.numel() != gather_index.numel():
+        raise RuntimeError("gather_scale_scatter: weight must have one entry per (gather, dst) pair")
+    n_src = int(X.shape[0])
+    plan_fwd = get_plan(dst_index, int(dim_size), gather_index, n_src)
+    plan_bwd = get_plan(gather_index, n_src, dst_index, int(dim_size))
+    if row_scale is not None:
+        _require_hip(row_scale, "row_scale")
+        if row_scale.numel() != n_src:
+            raise RuntimeError("gather_scale_scatter: row_scale must have one entry per row of X")
+    return _GatherScaleScatter.apply(X, weight, row_scale, plan_fwd, plan_bwd)
+
+
+# --------------------------------------------------------------------------- K6
+class _GatherRows(torch.autograd.Function):
+    """out[e] = table[index[e]]; backward = segmented reduce over the CSR by `index`"""
+
+    @staticmethod
+    def forward(ctx, table, plan: GraphPlan):
+        ctx.plan = plan
+        return _gather_rows(table.contiguous(), plan.dst32, plan.M)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        return _seg_reduce(ctx.plan, grad_out.contiguous(), None, None), None
+
+
+def gather_rows(table: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """``table[index]`` for a 2-D table and a 1-D int64 index (Modules/gnn_utils.py:61,134,152).
+    Forward is a whole-row HIP gather; backward is the atomics-free segmented reduce."""
+    _require_hip(table, "table")
+    if table.dim() != 2 or index.dim() != 1:
+        raise RuntimeError("gather_rows: table must be 2-D and index 1-D")
+    plan = get_plan(index, int(table.shape[0]))
+    return _GatherRows.apply(table, plan)
+
+
+def l1_row_scale(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """1 / max(||x_i||_1, eps): the per-row factor of F.normalize(x, p=1) (HGNN_GMM.py:269)"""
+    return 1.0 / x.abs().sum(dim=1).clamp_min(eps)

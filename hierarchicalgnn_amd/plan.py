@@ -1,0 +1,145 @@
+"""GraphPlan: the per-event, destination-sorted aggregation plan.
+
+The topology of an event is constant across every message-passing iteration of
+one forward (reference: EdgeClassifier/Models/IN.py:87-88 loops 14 cells over
+the same ``graph``; BipartiteClassification/Models/HGNN_GMM.py:93-94,:275-284
+loop 6 + 6), so the int64 -> int32 conversion, the stable sort by destination,
+the CSR and the degree-skew work list are built ONCE (``hgnn_plan_build`` in
+libhgnn_hip.so) and reused by every ``scatter_add`` / gather call.
+
+Plans are found again through a small cache keyed on the identity of the index
+tensor(s).  The cache keeps a strong reference to the tensors it is keyed on
+(so their storage cannot be recycled under a live key) and checks the tensors'
+in-place version counters, so it never returns a plan for different contents.
+Autograd / ``torch.utils.checkpoint`` recompute re-enters with the same index
+tensors and therefore hits the cache; no per-call state is kept.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_CACHE: "OrderedDict[tuple, GraphPlan]" = OrderedDict()
+_CACHE_SIZE = 16
+_STATS = {"built": 0, "hits": 0}
+
+
+def _i32(n, device):
+    return torch.empty(max(int(n), 1), dtype=torch.int32, device=device)
+
+
+class GraphPlan:
+    """Device-side plan for ``out[d] = sum_{e: dst[e]=d} w[e] * table[gather[e]]``.
+
+    dst_index    LongTensor[M]  destination row of every edge (e.g. ``graph[1]``)
+    dim_size     int            number of destination rows N
+    gather_index LongTensor[M]  optional source-table row of every edge
+                                (e.g. ``bipartite_graph[0]``); ``None`` means the
+                                table row of edge e is e itself (plain scatter_add)
+    n_src        int            rows of the source table (required with gather_index)
+    """
+
+    def __init__(self, dst_index: torch.Tensor, dim_size: int, gather_index: Optional[torch.Tensor] = None,
+                 n_src: Optional[int] = None, chunk: int = 0, validate: bool = True):
+        if not dst_index.is_cuda:
+            raise RuntimeError("GraphPlan needs a HIP device index tensor: hierarchicalgnn_amd has no CPU path")
+        if dst_index.dim() != 1 or dst_index.dtype != torch.int64:
+            raise RuntimeError("GraphPlan: index must be a 1-D int64 tensor (PyG edge_index row)")
+        if gather_index is not None:
+            if gather_index.shape != dst_index.shape or gather_index.dtype != torch.int64 \
+                    or gather_index.device != dst_index.device:
+                raise RuntimeError("GraphPlan: gather_index must match index in shape, dtype and device")
+            if n_src is None:
+                raise RuntimeError("GraphPlan: n_src is required with gather_index")
+        lib = _lib.load()
+        dev = dst_index.device
+        M = int(dst_index.numel())
+        N = int(dim_size)
+        R = int(n_src) if gather_index is not None else M
+        self.device = dev
+        self.M, self.N, self.R = M, N, R
+        c = _lib.HgnnPlan()
+        _lib.check(lib.hgnn_plan_dims(M, N, R, int(chunk), ctypes.byref(c)), "hgnn_plan_dims")
+        self.chunk = int(c.chunk)
+        self.max_partial = int(c.max_partial)
+        with torch.cuda.device(dev):
+            dst_c = dst_index.contiguous()
+            gat_c = gather_index.contiguous() if gather_index is not None else None
+            self.perm = _i32(M, dev)
+            self.src_row = _i32(M, dev)
+            self.dst32 = _i32(M, dev)
+            self.rowptr = _i32(N + 1, dev)
+            self.wi_begin = _i32(c.max_work, dev)
+            self.wi_end = _i32(c.max_work, dev)
+            self.wi_target = _i32(c.max_work, dev)
+            self.split_dst = _i32(c.max_split, dev)
+            self.split_pbegin = _i32(c.max_split + 1, dev)
+            self.counts = torch.zeros(8, dtype=torch.int32, device=dev)
+            for name in ("perm", "src_row", "dst32", "rowptr", "wi_begin", "wi_end", "wi_target",
+                         "split_dst", "split_pbegin", "counts"):
+                setattr(c, name, getattr(self, name).data_ptr())
+            nbytes = ctypes.c_size_t(0)
+            _lib.check(lib.hgnn_plan_workspace_bytes(M, N, ctypes.byref(nbytes)), "hgnn_plan_workspace_bytes")
+            ws = torch.empty(max(nbytes.value, 256), dtype=torch.uint8, device=dev)
+            _lib.check(lib.hgnn_plan_build(_lib.ptr(dst_c), _lib.ptr(gat_c), ctypes.byref(c), _lib.ptr(ws),
+                                           ws.numel(), _lib.current_stream(dev)), "hgnn_plan_build")
+            # `ws`, `dst_c`, `gat_c` are only used by kernels already enqueued on this
+            # stream; the caching allocator orders their reuse after them.
+        self.c = c
+        self._partial = {}
+        _STATS["built"] += 1
+        if validate:
+            # one host sync per plan (= per event), never per aggregation call
+            if int(self.counts[_lib.CNT_ERR].item()) != 0:
+                raise RuntimeError(
+                    f"GraphPlan: index out of range for dim_size={N}" +
+                    (f" / source rows={R}" if gather_index is not None else ""))
+
+    # scratch for the partial sums of split destinations, one buffer per feature width
+    def partial(self, F: int) -> torch.Tensor:
+        buf = self._partial.get(F)
+        if buf is None:
+            buf = torch.empty(max(self.max_partial, 1) * F, dtype=torch.float32, device=self.device)
+            self._partial[F] = buf
+        return buf
+
+    def counts_host(self):
+        c = self.counts.cpu().tolist()
+        return dict(work=c[_lib.CNT_WORK], split=c[_lib.CNT_SPLIT], partial=c[_lib.CNT_PARTIAL],
+                    err=c[_lib.CNT_ERR], valid=c[_lib.CNT_VALID])
+
+
+def _key(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.device.index)
+
+
+def get_plan(dst_index: torch.Tensor, dim_size: int, gather_index: Optional[torch.Tensor] = None,
+             n_src: Optional[int] = None) -> GraphPlan:
+    """cached GraphPlan for (dst_index, dim_size[, gather_index, n_src])"""
+    key = (_key(dst_index), int(dim_size), _key(gather_index), None if n_src is None else int(n_src))
+    hit = _CACHE.get(key)
+    if hit is not None:
+        _CACHE.move_to_end(key)
+        _STATS["hits"] += 1
+        return hit[0]
+    plan = GraphPlan(dst_index, dim_size, gather_index, n_src)
+    # the strong references below pin the storages the key's data_ptr()s refer to
+    _CACHE[key] = (plan, dst_index, gather_index)
+    while len(_CACHE) > _CACHE_SIZE:
+        _CACHE.popitem(last=False)
+    return plan
+
+
+def clear_plan_cache():
+    _CACHE.clear()
+
+
+def plan_cache_stats():
+    return dict(_STATS, size=len(_CACHE))

@@ -1,0 +1,32 @@
+"""Host-side mirror of the one helper of the reference's Modules/utils.py that is
+on the hot path: ``make_mlp`` (utils.py:169-196).
+
+It builds the same ``nn.Sequential`` (same sub-module indices, hence the same
+``state_dict`` keys: ``{0,3,6}.weight`` Linear, ``{1,4,7}.weight`` LayerNorm
+when ``layer_norm=True``), so reference checkpoints load unchanged.  The
+modules only HOLD the parameters; on an MI355X the cells evaluate them with the
+fused HIP/MFMA kernel (``fused_mlp``), not with these layers' own forward.
+"""
+from __future__ import annotations
+
+import torch.nn as nn
+
+
+def make_mlp(input_size, hidden_size, output_size, hidden_layers, hidden_activation="GELU",
+             output_activation="GELU", layer_norm=False):
+    """[Linear -> (LayerNorm) -> act] x (hidden_layers-1) -> Linear -> (LayerNorm -> act)"""
+    hidden_act = getattr(nn, hidden_activation)
+    out_act = getattr(nn, output_activation) if output_activation is not None else None
+    sizes = [input_size] + [hidden_size] * (hidden_layers - 1) + [output_size]
+    layers = []
+    for i in range(hidden_layers - 1):
+        layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+        if layer_norm:
+            layers.append(nn.LayerNorm(sizes[i + 1]))
+        layers.append(hidden_act())
+    layers.append(nn.Linear(sizes[-2], sizes[-1]))
+    if out_act is not None:
+        if layer_norm:
+            layers.append(nn.LayerNorm(sizes[-1]))
+        layers.append(out_act())
+    return nn.Sequential(*layers)

@@ -1,0 +1,133 @@
+/*
+ * hgnn_hip.h -- C ABI of libhgnn_hip.so: the MI355X (gfx950) message-passing
+ * engine behind the reference's operator interface.
+ *
+ * Every entry point takes plain device pointers, sizes and a hipStream_t (as
+ * void*), launches asynchronously on that stream, performs no allocation and no
+ * host synchronisation (graph-capturable), and returns an int status
+ * (HGNN_OK == 0).  hgnn_last_error() returns a thread-local message for the
+ * last non-zero status.  No torch types appear here: a binding only needs
+ * `tensor.data_ptr()` and the current stream handle.
+ *
+ * Reference interfaces these replace (paths relative to the reference root,
+ * clairesonglee/HierarchicalGNN):
+ *
+ *   hgnn_plan_build / hgnn_segment_reduce_f32
+ *       torch_scatter.scatter_add(src, index, dim=0, dim_size=N) as called at
+ *       Modules/gnn_utils.py:50 and :125 (edge -> node aggregation, "K1"),
+ *       Modules/gnn_utils.py:143 (weighted superedge -> supernode, "K4"),
+ *       and, with a gather index, the fused expressions
+ *       scatter_add(w * X[g], d, dim_size) at Modules/gnn_utils.py:124 ("K2"),
+ *       :142 ("K3") and, with a per-row L1 scale,
+ *       BipartiteClassification/Models/HGNN_GMM.py:269 ("K5").
+ *   hgnn_gather_rows_f32
+ *       the row gathers nodes[graph[0]], nodes[graph[1]] at
+ *       Modules/gnn_utils.py:61,134,152 ("K6"); also the backward of scatter_add.
+ *   hgnn_edge_dot_f32
+ *       backward of the weighted forms w.r.t. the weights (autograd of
+ *       Modules/gnn_utils.py:124,142,143).
+ */
+#ifndef HGNN_HIP_H
+#define HGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGNN_OK 0
+#define HGNN_ERR_INVALID_ARG 1
+#define HGNN_ERR_HIP 2
+#define HGNN_ERR_WORKSPACE 3
+#define HGNN_ERR_UNSUPPORTED 4
+
+#define HGNN_ABI_VERSION 1
+
+typedef void* hgnn_stream_t; /* hipStream_t */
+
+/* indices into hgnn_plan.counts (device int32[8]) */
+#define HGNN_CNT_WORK 0     /* number of work items                         */
+#define HGNN_CNT_SPLIT 1    /* number of destinations whose list was split  */
+#define HGNN_CNT_PARTIAL 2  /* number of partial rows                       */
+#define HGNN_CNT_ERR 3      /* !=0: an index was out of range (row dropped) */
+#define HGNN_CNT_VALID 4    /* rows with a valid destination (and source)   */
+
+/*
+ * A destination-sorted aggregation plan for one (index, dim_size) pair.  Built
+ * once per event, reused by every cell (the topology is constant across the
+ * 14 / 6+6 iterations of a forward: EdgeClassifier/Models/IN.py:87-88,
+ * BipartiteClassification/Models/HGNN_GMM.py:93-94,:275-284).  All arrays are
+ * device int32, allocated by the caller with the sizes hgnn_plan_dims() gives.
+ */
+typedef struct hgnn_plan {
+    int64_t n_rows;    /* M: rows of `index` (edges)                              */
+    int64_t n_dst;     /* N: dim_size                                             */
+    int64_t n_src;     /* R: rows of the source table (== M when no gather index) */
+    int32_t chunk;     /* longest list one wave sums; longer lists are split      */
+    int32_t has_gather;
+    int64_t max_work;     /* capacity of wi_*                                     */
+    int64_t max_split;    /* capacity of split_dst; split_pbegin has +1           */
+    int64_t max_partial;  /* rows of the partial-sum workspace                    */
+    int32_t* perm;        /* [M]  original position of the p-th dst-sorted row (stable) */
+    int32_t* src_row;     /* [M]  source-table row read at sorted position p      */
+    int32_t* dst32;       /* [M]  destination of ORIGINAL position e, -1 if invalid */
+    int32_t* rowptr;      /* [N+1] CSR by destination over sorted positions       */
+    int32_t* wi_begin;    /* [max_work]                                           */
+    int32_t* wi_end;      /* [max_work]                                           */
+    int32_t* wi_target;   /* [max_work] >=0: output row; <0: ~partial row         */
+    int32_t* split_dst;   /* [max_split]                                          */
+    int32_t* split_pbegin;/* [max_split+1] partial-row range of each split dst    */
+    int32_t* counts;      /* [8]                                                  */
+} hgnn_plan;
+
+int hgnn_abi_version(void);
+const char* hgnn_last_error(void);
+
+/* Tuning switches for A/B measurements ("nt_loads", "nt_stores"); process-wide. */
+int hgnn_set_option(const char* name, int value);
+
+/* Fills n_rows/n_dst/n_src/chunk/max_* of `plan` (pointers untouched).
+ * chunk <= 0 selects the default rule (quarter of a wave's share of the rows,
+ * clamped to [32, 512]). */
+int hgnn_plan_dims(int64_t n_rows, int64_t n_dst, int64_t n_src, int32_t chunk, hgnn_plan* plan);
+
+/* Bytes of scratch hgnn_plan_build needs (device memory, any 256-B aligned). */
+int hgnn_plan_workspace_bytes(int64_t n_rows, int64_t n_dst, size_t* bytes);
+
+/* dst_index: int64[M] destinations (PyG edge_index row / bipartite_graph row).
+ * gather_index: int64[M] source-table rows, or NULL (row e of the table is edge e).
+ * Out-of-range entries are dropped and flagged in counts[HGNN_CNT_ERR]. */
+int hgnn_plan_build(const int64_t* dst_index, const int64_t* gather_index, hgnn_plan* plan,
+                    void* workspace, size_t workspace_bytes, hgnn_stream_t stream);
+
+/* out[d,:] = sum_{p in list(d)} weight[perm[p]] * row_scale[src_row[p]] * src[src_row[p],:]
+ * weight (float[M], by ORIGINAL position) and row_scale (float[n_src]) may be NULL.
+ * out: float[N,F] (every row written, zeros for empty lists);
+ * partial: float[max_partial,F] scratch.  Deterministic: fixed summation order. */
+int hgnn_segment_reduce_f32(const hgnn_plan* plan, const float* src, int32_t F,
+                            const float* weight, const float* row_scale,
+                            float* out, float* partial, hgnn_stream_t stream);
+
+/* out[e,:] = weight[e] * row_scale[idx[e]] * table[idx[e],:]   (idx[e] < 0 -> zeros)
+ * idx: int32[M]; weight float[M] / row_scale float[table_rows] may be NULL. */
+int hgnn_gather_rows_f32(const float* table, int64_t table_rows, int32_t F,
+                         const int32_t* idx, int64_t M,
+                         const float* weight, const float* row_scale,
+                         float* out, hgnn_stream_t stream);
+
+/* out[e] = sum_f A[ai[e],f] * B[bi[e],f];  ai/bi int32[M] or NULL (identity);
+ * negative index -> 0. */
+int hgnn_edge_dot_f32(const float* A, const int32_t* ai, int64_t a_rows,
+                      const float* B, const int32_t* bi, int64_t b_rows,
+                      int32_t F, int64_t M, float* out, hgnn_stream_t stream);
+
+/* int64 -> int32 index conversion with range check (out-of-range -> -1, err flag set) */
+int hgnn_index_to_i32(const int64_t* idx, int64_t M, int64_t limit, int32_t* out,
+                      int32_t* err_flag, hgnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGNN_HIP_H */

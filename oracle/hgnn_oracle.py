@@ -1,0 +1,185 @@
+"""CPU ORACLE for the hierarchical-GNN message-passing hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  ``hierarchicalgnn_amd`` never imports anything under ``oracle/`` and has
+no CPU fallback for its HIP kernels.
+
+It is a plain restatement, in stock CPU PyTorch (fp32 by default, fp64 on
+request), of what the reference computes on this path.  Each function cites the
+reference file:line it follows (paths relative to the reference root).  The
+arithmetic of ``scatter_add`` itself lives in the un-vendored third-party
+package torch-scatter 2.0.9 (reference README.md:55); its CPU behaviour for the
+call shape used here (1-D index broadcast along features, ``dim=0``, fresh
+zero output of ``dim_size`` rows) is ``zeros.scatter_add_`` and is restated as
+such.
+
+Parity pin: ``tests/test_oracle_golden.py`` checks every function here against
+the fixtures in ``tests/golden/*.npz``, which were produced by importing and
+running the reference's own modules (``tests/golden/make_golden.py``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# ---------------------------------------------------------------------------
+# K1: scatter_add(src, index, dim=0, dim_size)   [torch_scatter; call sites
+#     Modules/gnn_utils.py:50,124,125,142,143; BipartiteClassification/Models/HGNN_GMM.py:269]
+# ---------------------------------------------------------------------------
+def scatter_add(src: Tensor, index: Tensor, dim: int = 0, dim_size: Optional[int] = None) -> Tensor:
+    if dim != 0:
+        raise ValueError("the hot path only uses dim=0")
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() else 0
+    out = torch.zeros((int(dim_size),) + tuple(src.shape[1:]), dtype=src.dtype)
+    idx = index.reshape(-1, *([1] * (src.dim() - 1))).expand_as(src)
+    return out.scatter_add_(0, idx, src)
+
+
+# ---------------------------------------------------------------------------
+# K7: make_mlp  [Modules/utils.py:169-196]
+#     [Linear -> (LayerNorm) -> act] x (n-1) -> Linear -> (LayerNorm -> act)
+#     Sequential indices: with layer_norm, layer i's Linear sits at 3*i, its
+#     LayerNorm at 3*i+1; without, Linear at 2*i.
+# ---------------------------------------------------------------------------
+def _act(name: Optional[str], x: Tensor) -> Tensor:
+    if name is None:
+        return x
+    if name == "GELU":  # nn.GELU() default approximate='none' (erf form)
+        return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    if name == "Tanh":
+        return torch.tanh(x)
+    if name == "ReLU":
+        return torch.relu(x)
+    if name == "SiLU":
+        return x * torch.sigmoid(x)
+    if name == "Sigmoid":
+        return torch.sigmoid(x)
+    raise ValueError(name)
+
+
+def _layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)  # biased variance, as nn.LayerNorm
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def mlp_apply(sd: Dict[str, Tensor], prefix: str, x: Tensor, hidden_layers: int,
+              hidden_activation: str = "GELU", output_activation: Optional[str] = "GELU",
+              layer_norm: bool = False) -> Tensor:
+    stride = 3 if layer_norm else 2
+    for i in range(hidden_layers - 1):
+        x = x @ sd[f"{prefix}{stride * i}.weight"].T + sd[f"{prefix}{stride * i}.bias"]
+        if layer_norm:
+            x = _layer_norm(x, sd[f"{prefix}{stride * i + 1}.weight"], sd[f"{prefix}{stride * i + 1}.bias"])
+        x = _act(hidden_activation, x)
+    j = stride * (hidden_layers - 1)
+    x = x @ sd[f"{prefix}{j}.weight"].T + sd[f"{prefix}{j}.bias"]
+    if output_activation is not None:
+        if layer_norm:
+            x = _layer_norm(x, sd[f"{prefix}{j + 1}.weight"], sd[f"{prefix}{j + 1}.bias"])
+        x = _act(output_activation, x)
+    return x
+
+
+# ---------------------------------------------------------------------------
+# InteractionGNNCell  [Modules/gnn_utils.py:17-71]
+# ---------------------------------------------------------------------------
+def ignn_node_update(sd, pfx, hp, nodes, edges, graph):
+    """gnn_utils.py:46-54"""
+    msg = scatter_add(edges, graph[1], dim=0, dim_size=nodes.shape[0])
+    inp = torch.cat([nodes, msg], dim=-1)
+    return mlp_apply(sd, pfx + "node_network.", inp, hp["nb_node_layer"], hp["hidden_activation"],
+                     hp["hidden_activation"], hp["layernorm"]) + nodes
+
+
+def edge_update(sd, pfx, hp, nodes, edges, graph, net="edge_network."):
+    """gnn_utils.py:57-64 (also :130-135 and :148-153: same expression)"""
+    inp = torch.cat([nodes[graph[0]], nodes[graph[1]], edges], dim=-1)
+    return mlp_apply(sd, pfx + net, inp, hp["nb_edge_layer"], hp["hidden_activation"], "Tanh",
+                     hp["layernorm"]) + edges
+
+
+def ignn_cell(sd, pfx, hp, nodes, edges, graph):
+    """gnn_utils.py:66-71 : node update first, the edge update sees UPDATED nodes"""
+    nodes = ignn_node_update(sd, pfx, hp, nodes, edges, graph)
+    edges = edge_update(sd, pfx, hp, nodes, edges, graph)
+    return nodes, edges
+
+
+# ---------------------------------------------------------------------------
+# HierarchicalGNNCell  [Modules/gnn_utils.py:73-169]
+# ---------------------------------------------------------------------------
+def hgnn_supernode_update(sd, pfx, hp, nodes, supernodes, superedges, bg, bw, sg, sw):
+    """gnn_utils.py:138-145 (K3 + K4)"""
+    node_msg = scatter_add(bw * nodes[bg[0]], bg[1], dim=0, dim_size=supernodes.shape[0])
+    attn_msg = scatter_add(superedges * sw, sg[1], dim=0, dim_size=supernodes.shape[0])
+    inp = torch.cat([supernodes, attn_msg, node_msg], dim=-1)
+    return mlp_apply(sd, pfx + "supernode_network.", inp, hp["nb_node_layer"], hp["hidden_activation"],
+                     hp["hidden_activation"], hp["layernorm"]) + supernodes
+
+
+def hgnn_node_update(sd, pfx, hp, nodes, edges, supernodes, graph, bg, bw):
+    """gnn_utils.py:120-127 (K2 + K1)"""
+    sn_msg = scatter_add(bw * supernodes[bg[1]], bg[0], dim=0, dim_size=nodes.shape[0])
+    e_msg = scatter_add(edges, graph[1], dim=0, dim_size=nodes.shape[0])
+    inp = torch.cat([nodes, e_msg, sn_msg], dim=-1)
+    return mlp_apply(sd, pfx + "node_network.", inp, hp["nb_node_layer"], hp["hidden_activation"],
+                     hp["hidden_activation"], hp["layernorm"]) + nodes
+
+
+def hgnn_cell(sd, pfx, hp, nodes, edges, supernodes, superedges, graph, bg, bw, sg, sw):
+    """gnn_utils.py:155-169 : supernode -> node -> superedge -> edge"""
+    supernodes = hgnn_supernode_update(sd, pfx, hp, nodes, supernodes, superedges, bg, bw, sg, sw)
+    nodes = hgnn_node_update(sd, pfx, hp, nodes, edges, supernodes, graph, bg, bw)
+    superedges = edge_update(sd, pfx, hp, supernodes, superedges, sg, net="superedge_network.")
+    edges = edge_update(sd, pfx, hp, nodes, edges, graph)
+    return nodes, edges, supernodes, superedges
+
+
+# ---------------------------------------------------------------------------
+# K5 initial super-node pooling  [BipartiteClassification/Models/HGNN_GMM.py:269]
+# ---------------------------------------------------------------------------
+def supernode_pool(nodes, bg, bw, n_super):
+    return scatter_add(F.normalize(nodes, p=1)[bg[0]] * bw, bg[1], dim=0, dim_size=n_super)
+
+
+# ---------------------------------------------------------------------------
+# EC-IN forward  [EdgeClassifier/Models/IN.py:80-128]
+# ---------------------------------------------------------------------------
+def ec_in_forward(sd, hp, x, graph):
+    directed = torch.cat([graph, graph.flip(0)], dim=1)                       # IN.py:122
+    nodes = mlp_apply(sd, "ignn_block.node_encoder.", x, hp["nb_node_layer"], hp["hidden_activation"],
+                      hp["hidden_activation"], hp["layernorm"])               # IN.py:84
+    edges = mlp_apply(sd, "ignn_block.edge_encoder.", torch.cat([x[directed[0]], x[directed[1]]], dim=1),
+                      hp["nb_edge_layer"], hp["hidden_activation"], hp["hidden_activation"],
+                      hp["layernorm"])                                        # IN.py:85
+    for i in range(hp["n_interaction_graph_iters"]):                          # IN.py:87-88
+        nodes, edges = ignn_cell(sd, f"ignn_block.ignn_cells.{i}.", hp, nodes, edges, directed)
+    e = graph.shape[1]
+    s = mlp_apply(sd, "edge_classifier.", torch.cat([edges[:e], edges[e:]], dim=1), hp["output_layers"],
+                  hp["hidden_output_activation"], None, hp["layernorm"])      # IN.py:126
+    return torch.sigmoid(s.squeeze())                                         # IN.py:127
+
+
+# ---------------------------------------------------------------------------
+# reference CPU aggregation, as timed for the cpu_baseline
+# ---------------------------------------------------------------------------
+def scatter_add_cpu_timed(src: Tensor, index: Tensor, dim_size: int, reps: int = 3):
+    """best-of-`reps` wall time (s) of the reference CPU arithmetic on all host threads"""
+    import time
+    idx = index.view(-1, 1).expand_as(src)
+    best = float("inf")
+    out = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = torch.zeros(dim_size, src.shape[1], dtype=src.dtype).scatter_add_(0, idx, src)
+        best = min(best, time.perf_counter() - t0)
+    return best, out

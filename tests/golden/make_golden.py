@@ -1,0 +1,474 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (it needs /root/reference, which never travels
+to the GPU box):
+
+    python tests/golden/make_golden.py
+
+What it does
+------------
+The reference (clairesonglee/HierarchicalGNN @ /root/reference) is pure Python
+but depends on packages that are not installed here (torch_scatter,
+torch_geometric, pytorch_lightning, cugraph, cudf, cupy, frnn).  We inject
+stand-in modules into ``sys.modules`` *before* importing the reference's own
+``Modules/gnn_utils.py``, ``Modules/utils.py``, ``EdgeClassifier/Models/IN.py``
+and ``BipartiteClassification/Models/HGNN_GMM.py`` and then run THE REFERENCE'S
+code (its cells, its make_mlp, its forward()) on seeded CPU fp32 inputs.  The
+inputs and outputs are stored as ``.npz`` (plain arrays, no pickle).
+
+Stand-ins, and why they do not weaken the pin:
+  * ``torch_scatter.scatter_add`` -> ``zeros(dim_size,F).scatter_add_(0, idx, src)``
+    which is torch-scatter 2.0.9's documented CPU behaviour (broadcast the 1-D
+    index, allocate zeros, Tensor.scatter_add_).  torch-scatter's source is not
+    in this image, so this one equivalence rests on the call-site semantics.
+    Every call is RECORDED, so K2-K5 fixtures come from the real call sites
+    (gnn_utils.py:124,125,142,143 and HGNN_GMM.py:269).
+  * pytorch_lightning / torch_geometric / wandb: containers only, no arithmetic.
+  * frnn / cugraph / cudf / cupy: brute-force kNN and scipy connected
+    components.  They only decide WHICH bipartite/super graph is built; the
+    graphs and weights they lead to are captured and stored with the fixture,
+    so the hot-path arithmetic that is pinned does not depend on them.
+
+Nothing from the reference's text is stored: fixtures are data only.
+"""
+import os
+import sys
+import math
+import types
+import tempfile
+
+sys.dont_write_bytecode = True
+# never read or write bytecode caches inside the (read-only) reference tree
+sys.pycache_prefix = tempfile.mkdtemp(prefix="golden_pyc_")
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = os.environ.get("HGNN_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+torch.set_num_threads(1)  # sequential CPU scatter_add_: arrival-order sums
+torch.use_deterministic_algorithms(True)
+
+SCATTER_LOG = []  # every scatter_add call made by reference code
+
+
+# --------------------------------------------------------------------------
+# stand-in modules
+# --------------------------------------------------------------------------
+def _scatter_add(src, index, dim=0, dim_size=None, out=None):
+    assert dim == 0 and index.dim() == 1
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() else 0
+    dim_size = int(dim_size)
+    res = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+    idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+    res = res.scatter_add(0, idx, src)
+    SCATTER_LOG.append(dict(src=src.detach().clone(), index=index.detach().clone(),
+                            dim_size=dim_size, out=res.detach().clone()))
+    return res
+
+
+def _scatter_mean(src, index, dim=0, dim_size=None):
+    dim_size = int(dim_size)
+    s = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+    idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+    s = s.scatter_add(0, idx, src)
+    c = torch.zeros(dim_size, dtype=src.dtype).scatter_add(0, index, torch.ones_like(index, dtype=src.dtype))
+    return s / c.clamp(min=1).view(-1, *([1] * (src.dim() - 1)))
+
+
+def _install_stubs():
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter_add = _scatter_add
+    ts.scatter_mean = _scatter_mean
+    ts.scatter_min = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError)
+    ts.scatter_max = ts.scatter_min
+    sys.modules["torch_scatter"] = ts
+
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(nn.Module):
+        def save_hyperparameters(self, hparams):
+            self._hp = dict(hparams)
+
+        @property
+        def hparams(self):
+            return self._hp
+
+        def log(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+    pl.LightningModule = LightningModule
+    sys.modules["pytorch_lightning"] = pl
+
+    tg = types.ModuleType("torch_geometric")
+    tgd = types.ModuleType("torch_geometric.data")
+
+    class Data(dict):
+        pass
+
+    tgd.Data = Data
+    tgd.DataLoader = object
+    tg.data = tgd
+    sys.modules["torch_geometric"] = tg
+    sys.modules["torch_geometric.data"] = tgd
+
+    cp = types.ModuleType("cupy")
+    cp.asarray = lambda t: np.asarray(t.detach().cpu() if torch.is_tensor(t) else t)
+    cp.vstack = np.vstack
+    sys.modules["cupy"] = cp
+
+    cudf = types.ModuleType("cudf")
+
+    class Series:
+        def __init__(self, t):
+            self.v = np.asarray(t.detach().cpu() if torch.is_tensor(t) else t)
+
+        def to_cupy(self):
+            return self.v
+
+    cudf.Series = Series
+    cudf.DataFrame = dict
+    sys.modules["cudf"] = cudf
+
+    cg = types.ModuleType("cugraph")
+
+    class Graph:
+        def from_cudf_edgelist(self, df, source, destination):
+            self.src = np.asarray(df[source])
+            self.dst = np.asarray(df[destination])
+
+    def connected_components(G):
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components as cc
+        if len(G.src) == 0:
+            raise ValueError("empty graph")
+        verts = np.unique(np.concatenate([G.src, G.dst]))
+        remap = {v: i for i, v in enumerate(verts)}
+        s = np.array([remap[v] for v in G.src])
+        d = np.array([remap[v] for v in G.dst])
+        n = len(verts)
+        _, labels = cc(coo_matrix((np.ones(len(s)), (s, d)), shape=(n, n)), directed=False)
+        return {"labels": labels.astype(np.int64), "vertex": verts.astype(np.int64)}
+
+    cg.Graph = Graph
+    comp = types.ModuleType("cugraph.components")
+    comp.connected_components = connected_components
+    cg.components = comp
+    st = types.ModuleType("cugraph.structure")
+    sym = types.ModuleType("cugraph.structure.symmetrize")
+
+    def symmetrize(src, dst):
+        a = np.stack([np.concatenate([src.v, dst.v]), np.concatenate([dst.v, src.v])])
+        a = np.unique(a, axis=1)
+        return Series(a[0]), Series(a[1])
+
+    sym.symmetrize = symmetrize
+    st.symmetrize = sym
+    cg.structure = st
+    sys.modules["cugraph"] = cg
+    sys.modules["cugraph.components"] = comp
+    sys.modules["cugraph.structure"] = st
+    sys.modules["cugraph.structure.symmetrize"] = sym
+
+    fr = types.ModuleType("frnn")
+
+    def frnn_grid_points(points1, points2, lengths1=None, lengths2=None, K=10, r=1.0, **kw):
+        p1, p2 = points1[0], points2[0]
+        d = torch.cdist(p1, p2)
+        k = min(K, p2.shape[0])
+        dist, idx = d.topk(k, dim=1, largest=False)
+        rr = float(r) if not torch.is_tensor(r) else float(r.item())
+        idx = torch.where(dist <= rr, idx, torch.full_like(idx, -1))
+        if k < K:
+            pad = torch.full((idx.shape[0], K - k), -1, dtype=idx.dtype)
+            idx = torch.cat([idx, pad], 1)
+            dist = torch.cat([dist, torch.zeros(dist.shape[0], K - k)], 1)
+        return (dist ** 2).unsqueeze(0), idx.unsqueeze(0), None, None
+
+    fr.frnn_grid_points = frnn_grid_points
+    sys.modules["frnn"] = fr
+
+
+def _import_reference():
+    _install_stubs()
+    sys.path.insert(0, os.path.join(REF, "Modules"))
+    import gnn_utils  # noqa
+    import utils  # noqa
+    from EdgeClassifier.Models.IN import EC_InteractionGNN
+    from BipartiteClassification.Models.HGNN_GMM import BC_HierarchicalGNN_GMM
+    return gnn_utils, utils, EC_InteractionGNN, BC_HierarchicalGNN_GMM
+
+
+def kaiming_init(model, gen):
+    """Same scheme as the reference's training_utils.kaiming_init (:48-58):
+    biases 0; '*0.weight' ~ N(0, 1/sqrt(fan_in)); other 2-D weights
+    ~ N(0, sqrt(2)/sqrt(fan_in)); 1-D weights (LayerNorm/BatchNorm) untouched.
+    (training_utils.py itself cannot be imported: it imports model packages that
+    need cuml; the scheme is restated here and is only used to make weights.)"""
+    for name, p in model.named_parameters():
+        if name.endswith(".bias"):
+            p.data.fill_(0)
+        elif p.dim() < 2:
+            continue
+        elif name.endswith("0.weight"):
+            p.data.copy_(torch.randn(p.shape, generator=gen) / math.sqrt(p.shape[1]))
+        else:
+            p.data.copy_(torch.randn(p.shape, generator=gen) * math.sqrt(2) / math.sqrt(p.shape[1]))
+    # non-trivial LayerNorm affine and biases so parity covers them
+    for name, p in model.named_parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn(p.shape, generator=gen))
+
+
+def sd_np(module, prefix="sd."):
+    return {prefix + k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def grads_np(module, prefix="grad."):
+    return {prefix + k: p.grad.detach().numpy().copy() for k, p in module.named_parameters()
+            if p.grad is not None}
+
+
+def synth_event(n_nodes, n_edges, gen):
+    """small TrackML-shaped event: hits on layers, edges between adjacent layers."""
+    layer = torch.randint(0, 10, (n_nodes,), generator=gen)
+    r = (layer.float() + 1) / 10
+    phi = (torch.rand(n_nodes, generator=gen) * 2 - 1)
+    z = torch.randn(n_nodes, generator=gen).clamp(-3, 3) / 3
+    x = torch.stack([r, phi, z], 1).float()
+    src = torch.randint(0, n_nodes, (n_edges,), generator=gen)
+    dst = torch.randint(0, n_nodes, (n_edges,), generator=gen)
+    keep = src != dst
+    return x, torch.stack([src[keep], dst[keep]])
+
+
+def synth_tracks(n_tracks, hits_per_track, gen):
+    """disconnected track-like chains so that connected components give many
+    clusters whichever way the reference's GMM cut falls."""
+    n = n_tracks * hits_per_track
+    tid = torch.arange(n_tracks).repeat_interleave(hits_per_track)
+    layer = torch.arange(hits_per_track).repeat(n_tracks)
+    phi0 = torch.rand(n_tracks, generator=gen) * 2 - 1
+    z0 = torch.randn(n_tracks, generator=gen).clamp(-3, 3) / 3
+    x = torch.stack([(layer.float() + 1) / 10,
+                     phi0[tid] + 0.01 * layer.float() + 0.002 * torch.randn(n, generator=gen),
+                     z0[tid] * (layer.float() + 1) / 10], 1).float()
+    i = torch.arange(n)
+    e1 = torch.stack([i[layer < hits_per_track - 1], i[layer < hits_per_track - 1] + 1])
+    e2 = torch.stack([i[layer < hits_per_track - 2], i[layer < hits_per_track - 2] + 2])
+    graph = torch.cat([e1, e2], 1)
+    graph = graph[:, torch.randperm(graph.shape[1], generator=gen)]
+    return x, graph
+
+
+# --------------------------------------------------------------------------
+def gen_k1_cases():
+    """K1 scatter_add(src, index, dim=0, dim_size) single-op cases."""
+    g = torch.Generator().manual_seed(101)
+    cases = {}
+
+    def add(name, src, index, dim_size):
+        out = _scatter_add(src, index, 0, dim_size)
+        cases[name + ".src"] = src.numpy()
+        cases[name + ".index"] = index.numpy()
+        cases[name + ".dim_size"] = np.int64(dim_size)
+        cases[name + ".out"] = out.numpy()
+
+    add("random_L32", torch.randn(500, 32, generator=g), torch.randint(0, 64, (500,), generator=g), 64)
+    add("random_L128", torch.randn(700, 128, generator=g), torch.randint(0, 90, (700,), generator=g), 90)
+    add("random_L256", torch.randn(600, 256, generator=g), torch.randint(0, 80, (600,), generator=g), 80)
+    add("random_L512", torch.randn(200, 512, generator=g), torch.randint(0, 30, (200,), generator=g), 30)
+    # empty destinations + dim_size > max(index)+1
+    add("sparse_dst", torch.randn(200, 64, generator=g), torch.randint(0, 10, (200,), generator=g) * 7, 100)
+    # duplicate heavy: everything to 3 rows (forces list splitting)
+    add("dup_heavy", torch.randn(1500, 128, generator=g), torch.randint(0, 3, (1500,), generator=g), 5)
+    # odd feature widths (scalar fallback)
+    add("odd_F3", torch.randn(100, 3, generator=g), torch.randint(0, 17, (100,), generator=g), 17)
+    add("F8", torch.randn(400, 8, generator=g), torch.randint(0, 50, (400,), generator=g), 50)
+    add("F248", torch.randn(150, 248, generator=g), torch.randint(0, 20, (150,), generator=g), 20)
+    # empty input
+    add("empty", torch.zeros(0, 32), torch.zeros(0, dtype=torch.long), 9)
+    # sorted index
+    idx = torch.sort(torch.randint(0, 33, (256,), generator=g)).values
+    add("sorted", torch.randn(256, 128, generator=g), idx, 33)
+    np.savez_compressed(os.path.join(OUT, "k1_scatter_add.npz"), **cases)
+    print("k1_scatter_add.npz", len(cases) // 4, "cases")
+
+
+def gen_ignn_cell(gnn_utils, latent, n_nodes, n_edges, seed):
+    g = torch.Generator().manual_seed(seed)
+    hp = dict(latent=latent, hidden=2 * latent, nb_edge_layer=2, nb_node_layer=3,
+              layernorm=True, hidden_activation="GELU")
+    cell = gnn_utils.InteractionGNNCell(hp)
+    kaiming_init(cell, g)
+    _, graph = synth_event(n_nodes, n_edges, g)
+    graph = torch.cat([graph, graph.flip(0)], 1)
+    nodes = torch.randn(n_nodes, latent, generator=g, requires_grad=True)
+    edges = torch.randn(graph.shape[1], latent, generator=g, requires_grad=True)
+    r1 = torch.randn(n_nodes, latent, generator=g)
+    r2 = torch.randn(graph.shape[1], latent, generator=g)
+    on, oe = cell(nodes, edges, graph)
+    ((on * r1).sum() + (oe * r2).sum()).backward()
+    d = dict(graph=graph.numpy(), nodes=nodes.detach().numpy(), edges=edges.detach().numpy(),
+             r_nodes=r1.numpy(), r_edges=r2.numpy(),
+             out_nodes=on.detach().numpy(), out_edges=oe.detach().numpy(),
+             grad_nodes=nodes.grad.numpy(), grad_edges=edges.grad.numpy(),
+             latent=np.int64(latent))
+    d.update(sd_np(cell))
+    d.update(grads_np(cell))
+    fn = f"ignn_cell_L{latent}.npz"
+    np.savez_compressed(os.path.join(OUT, fn), **d)
+    print(fn)
+
+
+def _bip(n_nodes, n_super, kb, ks, g):
+    bg0 = torch.arange(n_nodes).repeat_interleave(kb)
+    bg1 = torch.randint(0, n_super, (n_nodes * kb,), generator=g)
+    keep = torch.rand(n_nodes * kb, generator=g) > 0.15  # ragged: some kNN slots are -1 in the reference
+    bg = torch.stack([bg0[keep], bg1[keep]])
+    bw = torch.exp(0.5 * torch.randn(bg.shape[1], 1, generator=g))
+    bw = bw / bw.mean()
+    s0 = torch.arange(n_super).repeat_interleave(ks)
+    s1 = torch.randint(0, n_super, (n_super * ks,), generator=g)
+    sg = torch.stack([torch.cat([s0, s1]), torch.cat([s1, s0])])
+    sg = torch.unique(sg, dim=1)
+    sw = torch.sigmoid(torch.randn(sg.shape[1], 1, generator=g))
+    sw = sw / sw.mean()
+    return bg, bw, sg, sw
+
+
+def gen_hgnn_cell(gnn_utils, latent, n_nodes, n_edges, n_super, seed):
+    g = torch.Generator().manual_seed(seed)
+    hp = dict(latent=latent, hidden=2 * latent, nb_edge_layer=2, nb_node_layer=3,
+              layernorm=True, hidden_activation="GELU")
+    cell = gnn_utils.HierarchicalGNNCell(hp)
+    kaiming_init(cell, g)
+    _, graph = synth_event(n_nodes, n_edges, g)
+    graph = torch.cat([graph, graph.flip(0)], 1)
+    bg, bw, sg, sw = _bip(n_nodes, n_super, 5, 4, g)
+    bw.requires_grad_(True)
+    sw.requires_grad_(True)
+    nodes = torch.randn(n_nodes, latent, generator=g, requires_grad=True)
+    edges = torch.randn(graph.shape[1], latent, generator=g, requires_grad=True)
+    sn = torch.randn(n_super, latent, generator=g, requires_grad=True)
+    se = torch.randn(sg.shape[1], latent, generator=g, requires_grad=True)
+    rs = [torch.randn(t.shape, generator=g) for t in (nodes, edges, sn, se)]
+    outs = cell(nodes, edges, sn, se, graph, bg, bw, sg, sw)
+    sum((o * r).sum() for o, r in zip(outs, rs)).backward()
+    d = dict(graph=graph.numpy(), bipartite_graph=bg.numpy(), bipartite_edge_weights=bw.detach().numpy(),
+             super_graph=sg.numpy(), super_edge_weights=sw.detach().numpy(),
+             nodes=nodes.detach().numpy(), edges=edges.detach().numpy(),
+             supernodes=sn.detach().numpy(), superedges=se.detach().numpy(),
+             latent=np.int64(latent))
+    for nm, o, r, i in zip(("nodes", "edges", "supernodes", "superedges"), outs, rs, (nodes, edges, sn, se)):
+        d["out_" + nm] = o.detach().numpy()
+        d["r_" + nm] = r.numpy()
+        d["grad_" + nm] = i.grad.numpy()
+    d["grad_bipartite_edge_weights"] = bw.grad.numpy()
+    d["grad_super_edge_weights"] = sw.grad.numpy()
+    d.update(sd_np(cell))
+    d.update(grads_np(cell))
+    fn = f"hgnn_cell_L{latent}.npz"
+    np.savez_compressed(os.path.join(OUT, fn), **d)
+    print(fn)
+
+
+def gen_ec_in(EC, latent=32):
+    """BASELINE config 1: flat EC-IN, latent=32, full forward()."""
+    g = torch.Generator().manual_seed(303)
+    hp = dict(spatial_channels=3, latent=latent, hidden=2 * latent, n_interaction_graph_iters=14,
+              nb_node_layer=3, nb_edge_layer=2, output_layers=3, hidden_output_activation="GELU",
+              hidden_activation="GELU", layernorm=True, share_weight=False)
+    model = EC(hp)
+    kaiming_init(model, g)
+    x, graph = synth_event(2000, 12000, g)
+    scores = model(x.clone(), graph)
+    d = dict(x=x.numpy(), edge_index=graph.numpy(), scores=scores.detach().numpy(),
+             n_params=np.int64(sum(p.numel() for p in model.parameters())))
+    d.update({"hp." + k: np.array(v) for k, v in hp.items()})
+    d.update(sd_np(model))
+    np.savez_compressed(os.path.join(OUT, f"ec_in_L{latent}.npz"), **d)
+    print(f"ec_in_L{latent}.npz params", int(d["n_params"]))
+
+
+def gen_bc_hgnn(BC, latent=32):
+    """BASELINE config 3 shape at small latent: BC-HGNN-GMM forward with every
+    scatter_add call site captured (K1..K5) and the tensors that enter the
+    HierarchicalGNNCell loop, so stand-in kNN/CC choices do not matter."""
+    g = torch.Generator().manual_seed(404)
+    torch.manual_seed(404)
+    np.random.seed(404)
+    hp = dict(spatial_channels=3, latent=latent, hidden=2 * latent, emb_dim=8,
+              n_interaction_graph_iters=2, n_hierarchical_graph_iters=2,
+              nb_node_layer=3, nb_edge_layer=2, output_layers=3, hidden_output_activation="Tanh",
+              hidden_activation="GELU", layernorm=True, share_weight=False,
+              bipartitegraph_sparsity=5, supergraph_sparsity=10, min_cluster_size=3,
+              cluster_granularity=5)
+    model = BC(hp)
+    kaiming_init(model, g)
+    model.eval()  # freeze BatchNorm1d(1) stats / knn_radius EMA: forward is then a pure function
+    model.hgnn_block.super_graph_construction.knn_radius.fill_(2.0)
+    model.hgnn_block.bipartite_graph_construction.knn_radius.fill_(2.0)
+    x, graph = synth_tracks(70, 9, g)
+
+    # capture the arguments of every HierarchicalGNNCell call
+    cell_calls = []
+    for cell in model.hgnn_block.hgnn_cells:
+        cell.register_forward_hook(
+            lambda m, inp, out: cell_calls.append(([t.detach().clone() for t in inp],
+                                                    [t.detach().clone() for t in out])))
+    SCATTER_LOG.clear()
+    bg, bscores, emb = model(x.clone(), graph)
+    d = dict(x=x.numpy(), edge_index=graph.numpy(), bipartite_graph=bg.numpy(),
+             bipartite_scores=bscores.detach().numpy(), embeddings=emb.detach().numpy())
+    d.update({"hp." + k: np.array(v) for k, v in hp.items()})
+    d.update(sd_np(model))
+    names = ["nodes", "edges", "supernodes", "superedges", "graph", "bipartite_graph",
+             "bipartite_edge_weights", "super_graph", "super_edge_weights"]
+    for i, (inp, out) in enumerate(cell_calls):
+        for nm, t in zip(names, inp):
+            d[f"cell{i}.in.{nm}"] = t.numpy()
+        for nm, t in zip(names[:4], out):
+            d[f"cell{i}.out.{nm}"] = t.numpy()
+    for i, c in enumerate(SCATTER_LOG):
+        d[f"scatter{i}.src"] = c["src"].numpy()
+        d[f"scatter{i}.index"] = c["index"].numpy()
+        d[f"scatter{i}.dim_size"] = np.int64(c["dim_size"])
+        d[f"scatter{i}.out"] = c["out"].numpy()
+    d["n_scatter"] = np.int64(len(SCATTER_LOG))
+    d["n_cells"] = np.int64(len(cell_calls))
+    np.savez_compressed(os.path.join(OUT, f"bc_hgnn_L{latent}.npz"), **d)
+    print(f"bc_hgnn_L{latent}.npz scatter calls", len(SCATTER_LOG), "supernodes",
+          cell_calls[0][0][2].shape[0], "bipartite edges", bg.shape[1])
+
+
+def gen_pool(latent=64):
+    """K5 initial super-node pooling expression, HGNN_GMM.py:269, in isolation
+    (same torch expression the reference evaluates there)."""
+    g = torch.Generator().manual_seed(505)
+    n, s = 400, 23
+    nodes = torch.randn(n, latent, generator=g)
+    bg, bw, _, _ = _bip(n, s, 5, 4, g)
+    out = _scatter_add((nn.functional.normalize(nodes, p=1)[bg[0]]) * bw, bg[1], dim=0, dim_size=s)
+    np.savez_compressed(os.path.join(OUT, "k5_pool.npz"), nodes=nodes.numpy(), bipartite_graph=bg.numpy(),
+                        bipartite_edge_weights=bw.numpy(), out=out.numpy())
+    print("k5_pool.npz")
+
+
+if __name__ == "__main__":
+    gnn_utils, utils, EC, BC = _import_reference()
+    gen_k1_cases()
+    gen_pool()
+    gen_ignn_cell(gnn_utils, 32, 150, 700, 201)
+    gen_ignn_cell(gnn_utils, 128, 120, 500, 202)
+    gen_hgnn_cell(gnn_utils, 32, 150, 600, 17, 211)
+    gen_hgnn_cell(gnn_utils, 64, 100, 400, 11, 212)
+    gen_ec_in(EC, 32)
+    gen_bc_hgnn(BC, 32)

@@ -1,0 +1,75 @@
+"""CPU-only checks of the drop-in boundary: libhgnn_hip.so loads, exports every
+symbol include/hgnn_hip.h declares, and its host-side entry points behave."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import conftest
+from hierarchicalgnn_amd import _lib
+
+HEADER = os.path.join(conftest.ROOT, "include", "hgnn_hip.h")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hgnn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_is_built_and_loads():
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m hierarchicalgnn_amd.build` (or __graft_entry__.build())"
+    lib = _lib.load()
+    assert lib.hgnn_abi_version() == _lib.ABI_VERSION
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 10
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/hgnn_hip.h but not exported"
+    assert set(_lib.declared_symbols()) == set(names), "python binding and header disagree"
+
+
+def test_header_abi_version_matches_binding():
+    m = re.search(r"#define\s+HGNN_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    assert int(m.group(1)) == _lib.ABI_VERSION
+
+
+def test_plan_dims_host_logic():
+    lib = _lib.load()
+    p = _lib.HgnnPlan()
+    _lib.check(lib.hgnn_plan_dims(2_000_000, 120_000, 2_000_000, 0, ctypes.byref(p)))
+    assert p.chunk == 2_000_000 // 4096 // 4 == 122
+    assert p.max_work >= 120_000 + 2_000_000 // p.chunk
+    assert p.max_partial >= 2 * (2_000_000 // p.chunk)
+    _lib.check(lib.hgnn_plan_dims(100, 10, 100, 0, ctypes.byref(p)))
+    assert p.chunk == 32  # clamped
+    _lib.check(lib.hgnn_plan_dims(100, 10, 100, 7, ctypes.byref(p)))
+    assert p.chunk == 7
+    rc = lib.hgnn_plan_dims(-1, 10, 10, 0, ctypes.byref(p))
+    assert rc != 0 and b"negative" in lib.hgnn_last_error()
+    rc = lib.hgnn_plan_dims(1 << 33, 10, 10, 0, ctypes.byref(p))
+    assert rc != 0
+
+
+def test_plan_struct_layout_matches_header():
+    # 3*8 + 2*4 + 3*8 + 10 pointers
+    assert ctypes.sizeof(_lib.HgnnPlan) == 24 + 8 + 24 + 80
+
+
+def test_unknown_option_is_an_error():
+    lib = _lib.load()
+    assert lib.hgnn_set_option(b"nt_loads", 1) == 0
+    assert lib.hgnn_set_option(b"no_such_option", 1) != 0
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    import torch
+    import hierarchicalgnn_amd as H
+    with pytest.raises(RuntimeError, match="HIP device"):
+        H.scatter_add(torch.zeros(4, 8), torch.zeros(4, dtype=torch.long), dim=0, dim_size=2)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        H.gather_rows(torch.zeros(4, 8), torch.zeros(4, dtype=torch.long))

@@ -1,0 +1,78 @@
+"""GPU parity of the module-level boundary: InteractionGNNCell / HierarchicalGNNCell
+loaded with the REFERENCE's state_dict (fixtures produced by running the
+reference's own classes) reproduce its outputs and gradients."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _hp(latent, ckpt=True):
+    return dict(latent=latent, hidden=2 * latent, nb_edge_layer=2, nb_node_layer=3, layernorm=True,
+                hidden_activation="GELU", checkpointing=ckpt)
+
+
+def _load(cell, z, prefix="sd."):
+    sd = {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+    missing, unexpected = cell.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return cell.cuda()
+
+
+@pytest.mark.parametrize("latent,ckpt", [(32, True), (32, False), (128, True)])
+def test_interaction_cell(latent, ckpt):
+    import hierarchicalgnn_amd as H
+    z = load_golden(f"ignn_cell_L{latent}.npz")
+    cell = _load(H.InteractionGNNCell(_hp(latent, ckpt)), z)
+    nodes = torch.from_numpy(z["nodes"]).cuda().requires_grad_(True)
+    edges = torch.from_numpy(z["edges"]).cuda().requires_grad_(True)
+    graph = torch.from_numpy(z["graph"]).cuda()
+    on, oe = cell(nodes, edges, graph)
+    assert rel_err(on.detach().cpu().numpy(), z["out_nodes"]) <= TOL
+    assert rel_err(oe.detach().cpu().numpy(), z["out_edges"]) <= TOL
+    ((on * torch.from_numpy(z["r_nodes"]).cuda()).sum() + (oe * torch.from_numpy(z["r_edges"]).cuda()).sum()).backward()
+    assert rel_err(nodes.grad.cpu().numpy(), z["grad_nodes"]) <= TOL
+    assert rel_err(edges.grad.cpu().numpy(), z["grad_edges"]) <= TOL
+    for k, p in cell.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), z["grad." + k]) <= TOL, k
+
+
+@pytest.mark.parametrize("latent", [32, 64])
+def test_hierarchical_cell(latent):
+    import hierarchicalgnn_amd as H
+    z = load_golden(f"hgnn_cell_L{latent}.npz")
+    cell = _load(H.HierarchicalGNNCell(_hp(latent)), z)
+    names = ("nodes", "edges", "supernodes", "superedges")
+    t = {k: torch.from_numpy(z[k]).cuda().requires_grad_(True)
+         for k in names + ("bipartite_edge_weights", "super_edge_weights")}
+    outs = cell(t["nodes"], t["edges"], t["supernodes"], t["superedges"],
+                torch.from_numpy(z["graph"]).cuda(), torch.from_numpy(z["bipartite_graph"]).cuda(),
+                t["bipartite_edge_weights"], torch.from_numpy(z["super_graph"]).cuda(), t["super_edge_weights"])
+    for nm, o in zip(names, outs):
+        assert rel_err(o.detach().cpu().numpy(), z["out_" + nm]) <= TOL, nm
+    sum((o * torch.from_numpy(z["r_" + nm]).cuda()).sum() for nm, o in zip(names, outs)).backward()
+    for nm in t:
+        assert rel_err(t[nm].grad.cpu().numpy(), z["grad_" + nm]) <= TOL, nm
+    for k, p in cell.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), z["grad." + k]) <= TOL, k
+
+
+def test_bc_hgnn_cell_loop_from_reference_forward():
+    """the HierarchicalGNNCell inputs/outputs captured inside the reference's BC-HGNN-GMM forward"""
+    import hierarchicalgnn_amd as H
+    z = load_golden("bc_hgnn_L32.npz")
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    names = ["nodes", "edges", "supernodes", "superedges", "graph", "bipartite_graph",
+             "bipartite_edge_weights", "super_graph", "super_edge_weights"]
+    for i in range(int(z["n_cells"])):
+        cell = _load(H.HierarchicalGNNCell(hp), z, prefix=f"sd.hgnn_block.hgnn_cells.{i}.")
+        args = [torch.from_numpy(z[f"cell{i}.in.{n}"]).cuda() for n in names]
+        with torch.no_grad():
+            outs = cell(*args)
+        for nm, o in zip(names[:4], outs):
+            assert rel_err(o.cpu().numpy(), z[f"cell{i}.out.{nm}"]) <= TOL, (i, nm)

@@ -1,0 +1,120 @@
+"""Pins the CPU oracle (oracle/) against the golden fixtures produced by running the
+reference's own modules (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import hgnn_oracle as O
+from oracle import c_oracle as C
+
+TOL = 2e-6  # oracle vs reference: same arithmetic, only op-fusion / summation-order noise
+
+
+def _cases(npz):
+    return sorted({k.split(".")[0] for k in npz.files})
+
+
+def test_k1_scatter_add_torch_oracle():
+    z = load_golden("k1_scatter_add.npz")
+    for c in _cases(z):
+        out = O.scatter_add(torch.from_numpy(z[c + ".src"]), torch.from_numpy(z[c + ".index"]),
+                            dim=0, dim_size=int(z[c + ".dim_size"]))
+        assert out.shape == z[c + ".out"].shape, c
+        assert rel_err(out.numpy(), z[c + ".out"]) <= TOL, c
+
+
+def test_k1_scatter_add_c_oracle_bit_exact():
+    """sequential arrival-order sum: the C loop reproduces the fixture bit for bit"""
+    z = load_golden("k1_scatter_add.npz")
+    for c in _cases(z):
+        out = C.scatter_add(z[c + ".src"], z[c + ".index"], int(z[c + ".dim_size"]))
+        assert np.array_equal(out, z[c + ".out"]), c
+
+
+def test_k5_pool():
+    z = load_golden("k5_pool.npz")
+    nodes = torch.from_numpy(z["nodes"])
+    bg = torch.from_numpy(z["bipartite_graph"])
+    bw = torch.from_numpy(z["bipartite_edge_weights"])
+    out = O.supernode_pool(nodes, bg, bw, z["out"].shape[0])
+    assert rel_err(out.numpy(), z["out"]) <= TOL
+    rs = 1.0 / np.maximum(np.abs(z["nodes"]).sum(1), 1e-12)
+    outc = C.gather_scale_scatter(z["nodes"], z["bipartite_graph"][0], z["bipartite_graph"][1], z["out"].shape[0],
+                                  weight=z["bipartite_edge_weights"], row_scale=rs.astype(np.float32))
+    assert rel_err(outc, z["out"]) <= 1e-6
+
+
+def _sd(z, prefix="sd."):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def _hp(latent):
+    return dict(latent=latent, hidden=2 * latent, nb_edge_layer=2, nb_node_layer=3, layernorm=True,
+                hidden_activation="GELU")
+
+
+@pytest.mark.parametrize("latent", [32, 128])
+def test_ignn_cell_forward_and_grads(latent):
+    z = load_golden(f"ignn_cell_L{latent}.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(z).items()}
+    nodes = torch.from_numpy(z["nodes"]).requires_grad_(True)
+    edges = torch.from_numpy(z["edges"]).requires_grad_(True)
+    graph = torch.from_numpy(z["graph"])
+    on, oe = O.ignn_cell(sd, "", _hp(latent), nodes, edges, graph)
+    assert rel_err(on.detach().numpy(), z["out_nodes"]) <= TOL
+    assert rel_err(oe.detach().numpy(), z["out_edges"]) <= TOL
+    ((on * torch.from_numpy(z["r_nodes"])).sum() + (oe * torch.from_numpy(z["r_edges"])).sum()).backward()
+    assert rel_err(nodes.grad.numpy(), z["grad_nodes"]) <= 1e-5
+    assert rel_err(edges.grad.numpy(), z["grad_edges"]) <= 1e-5
+    for k, v in sd.items():
+        assert rel_err(v.grad.numpy(), z["grad." + k]) <= 1e-5, k
+
+
+@pytest.mark.parametrize("latent", [32, 64])
+def test_hgnn_cell_forward_and_grads(latent):
+    z = load_golden(f"hgnn_cell_L{latent}.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sd(z).items()}
+    t = {k: torch.from_numpy(z[k]) for k in ("nodes", "edges", "supernodes", "superedges",
+                                              "bipartite_edge_weights", "super_edge_weights")}
+    for v in t.values():
+        v.requires_grad_(True)
+    outs = O.hgnn_cell(sd, "", _hp(latent), t["nodes"], t["edges"], t["supernodes"], t["superedges"],
+                       torch.from_numpy(z["graph"]), torch.from_numpy(z["bipartite_graph"]),
+                       t["bipartite_edge_weights"], torch.from_numpy(z["super_graph"]), t["super_edge_weights"])
+    names = ("nodes", "edges", "supernodes", "superedges")
+    for nm, o in zip(names, outs):
+        assert rel_err(o.detach().numpy(), z["out_" + nm]) <= TOL, nm
+    sum((o * torch.from_numpy(z["r_" + nm])).sum() for nm, o in zip(names, outs)).backward()
+    for nm in names + ("bipartite_edge_weights", "super_edge_weights"):
+        assert rel_err(t[nm].grad.numpy(), z["grad_" + nm]) <= 1e-5, nm
+    for k, v in sd.items():
+        assert rel_err(v.grad.numpy(), z["grad." + k]) <= 1e-5, k
+
+
+def test_ec_in_forward_config1():
+    """BASELINE config 1: flat EC-IN, latent=32, CPU"""
+    z = load_golden("ec_in_L32.npz")
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    scores = O.ec_in_forward(_sd(z), hp, torch.from_numpy(z["x"]), torch.from_numpy(z["edge_index"]))
+    assert scores.shape == z["scores"].shape
+    assert np.abs(scores.numpy() - z["scores"]).max() <= 5e-6
+    assert int(z["n_params"]) == 286977
+
+
+def test_bc_hgnn_call_sites_and_cells():
+    """every scatter_add call site of a BC-HGNN-GMM forward (K1..K5) and the cell loop"""
+    z = load_golden("bc_hgnn_L32.npz")
+    for i in range(int(z["n_scatter"])):
+        out = O.scatter_add(torch.from_numpy(z[f"scatter{i}.src"]), torch.from_numpy(z[f"scatter{i}.index"]),
+                            dim=0, dim_size=int(z[f"scatter{i}.dim_size"]))
+        assert rel_err(out.numpy(), z[f"scatter{i}.out"]) <= TOL, i
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    sd = _sd(z)
+    names = ["nodes", "edges", "supernodes", "superedges", "graph", "bipartite_graph",
+             "bipartite_edge_weights", "super_graph", "super_edge_weights"]
+    for i in range(int(z["n_cells"])):
+        args = [torch.from_numpy(z[f"cell{i}.in.{n}"]) for n in names]
+        outs = O.hgnn_cell(sd, f"hgnn_block.hgnn_cells.{i}.", hp, *args)
+        for nm, o in zip(names[:4], outs):
+            assert rel_err(o.numpy(), z[f"cell{i}.out.{nm}"]) <= TOL, (i, nm)
