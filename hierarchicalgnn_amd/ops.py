@@ -132,7 +132,10 @@ def scatter_add(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size: 
     elif plan.M != index.numel() or plan.N != dim_size or plan.c.has_gather:
         raise RuntimeError("hierarchicalgnn_amd.scatter_add: plan does not match index/dim_size")
     trailing = tuple(src.shape[1:])
-    src2d = src.reshape(src.shape[0], -1)
+    width = 1
+    for t in trailing:
+        width *= int(t)
+    src2d = src.reshape(src.shape[0], width)
     if weight is not None:
         _require_hip(weight, "weight")
         if weight.numel() != src.shape[0]:
