@@ -30,8 +30,9 @@ __device__ __forceinline__ f32x4 ld4(const float* p, bool nt) {
     return nt ? __builtin_nontemporal_load((const f32x4*)p) : *(const f32x4*)p;
 }
 
-template <int RL, int VPL, int U, bool HAS_W, bool HAS_RS, bool NT>
-__global__ __launch_bounds__(256) void k_seg_reduce(
+// TAG distinguishes the main pass (0) from the partial-sum combine pass (1) in profiles.
+template <int RL, int VPL, int U, bool HAS_W, bool HAS_RS, bool NT, int TAG, int WPB, bool XCD>
+__global__ __launch_bounds__(WPB * 64) void k_seg_reduce(
     const float* __restrict__ src, int F, int nvec, const int32_t* __restrict__ src_row,
     const int32_t* __restrict__ perm, const float* __restrict__ weight,
     const float* __restrict__ row_scale, const int32_t* __restrict__ wi_begin,
@@ -40,7 +41,14 @@ __global__ __launch_bounds__(256) void k_seg_reduce(
     float* __restrict__ partial) {
     constexpr int G = 64 / RL;
     const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    int64_t bid = blockIdx.x;
+    if (XCD) {
+        // blocks are dealt round-robin over the 8 XCDs: give each XCD a contiguous run of
+        // work items so that neighbouring lists (which share index cache lines) share an L2.
+        const int64_t per_xcd = (gridDim.x + 7) / 8;
+        bid = (bid % 8) * per_xcd + bid / 8;
+    }
+    const int64_t item = bid * WPB + (threadIdx.x >> 6);
     const int n_items = *n_items_ptr;
     if (item >= n_items || item >= max_items) return;
     const int begin = __builtin_amdgcn_readfirstlane(wi_begin[item]);
@@ -317,22 +325,52 @@ struct SegArgs {
     float *out, *partial;
 };
 
-template <int RL, int VPL, int U, bool W, bool RS>
-static void launch_seg(const SegArgs& a, hipStream_t s) {
-    const unsigned grid = (unsigned)ceil_div(a.max_items, kWavesPerBlock);
+static int g_opt_seg_unroll = 16;  // rows in flight per wave for 1-KiB rows (F in (128,256])
+static int g_opt_seg_wpb = 16;     // waves per workgroup
+static int g_opt_seg_xcd = 0;      // XCD-contiguous work-item mapping
+
+template <int RL, int VPL, int U, bool W, bool RS, bool NT, int TAG, int WPB, bool XCD>
+static void launch_seg3(const SegArgs& a, hipStream_t s) {
+    unsigned grid = (unsigned)ceil_div(a.max_items, WPB);
     if (grid == 0) return;
+    if (XCD) grid = (grid + 7) / 8 * 8;
     const int nvec = a.F / 4;
-    if (g_opt_nt_loads)
-        k_seg_reduce<RL, VPL, U, W, RS, true><<<grid, kBlock, 0, s>>>(
-            a.src, a.F, nvec, a.src_row, a.perm, a.weight, a.row_scale, a.wi_begin, a.wi_end,
-            a.wi_target, a.n_items, a.max_items, a.out, a.partial);
-    else
-        k_seg_reduce<RL, VPL, U, W, RS, false><<<grid, kBlock, 0, s>>>(
-            a.src, a.F, nvec, a.src_row, a.perm, a.weight, a.row_scale, a.wi_begin, a.wi_end,
-            a.wi_target, a.n_items, a.max_items, a.out, a.partial);
+    k_seg_reduce<RL, VPL, U, W, RS, NT, TAG, WPB, XCD><<<grid, WPB * 64, 0, s>>>(
+        a.src, a.F, nvec, a.src_row, a.perm, a.weight, a.row_scale, a.wi_begin, a.wi_end,
+        a.wi_target, a.n_items, a.max_items, a.out, a.partial);
 }
 
-template <bool W, bool RS>
+template <int RL, int VPL, int U, bool W, bool RS, int TAG>
+static void launch_seg(const SegArgs& a, hipStream_t s) {
+    if (g_opt_nt_loads)
+        launch_seg3<RL, VPL, U, W, RS, true, TAG, 4, false>(a, s);
+    else
+        launch_seg3<RL, VPL, U, W, RS, false, TAG, 4, false>(a, s);
+}
+
+// tunable instantiations of the headline shape (1-KiB rows, no weights): A/B knobs
+template <int TAG>
+static void launch_seg_tuned(const SegArgs& a, hipStream_t s) {
+    const int u = g_opt_seg_unroll, w = g_opt_seg_wpb;
+    const bool x = g_opt_seg_xcd != 0, nt = g_opt_nt_loads != 0;
+#define HGNN_T(U_, W_)                                                                       \
+    do {                                                                                     \
+        if (nt && x) launch_seg3<64, 1, U_, false, false, true, TAG, W_, true>(a, s);        \
+        else if (nt) launch_seg3<64, 1, U_, false, false, true, TAG, W_, false>(a, s);       \
+        else if (x) launch_seg3<64, 1, U_, false, false, false, TAG, W_, true>(a, s);        \
+        else launch_seg3<64, 1, U_, false, false, false, TAG, W_, false>(a, s);              \
+    } while (0)
+    if (w == 8) {
+        if (u <= 4) HGNN_T(4, 8); else if (u <= 8) HGNN_T(8, 8); else HGNN_T(16, 8);
+    } else if (w == 16) {
+        if (u <= 4) HGNN_T(4, 16); else if (u <= 8) HGNN_T(8, 16); else HGNN_T(16, 16);
+    } else {
+        if (u <= 2) HGNN_T(2, 4); else if (u <= 4) HGNN_T(4, 4); else if (u <= 8) HGNN_T(8, 4); else HGNN_T(16, 4);
+    }
+#undef HGNN_T
+}
+
+template <bool W, bool RS, int TAG>
 static int dispatch_seg(const SegArgs& a, hipStream_t s) {
     const int F = a.F;
     if (F % 4 != 0 || F > 1024) {
@@ -345,13 +383,15 @@ static int dispatch_seg(const SegArgs& a, hipStream_t s) {
         return HGNN_OK;
     }
     const int nvec = F / 4;
-    if (nvec <= 4) launch_seg<4, 1, 4, W, RS>(a, s);
-    else if (nvec <= 8) launch_seg<8, 1, 4, W, RS>(a, s);
-    else if (nvec <= 16) launch_seg<16, 1, 4, W, RS>(a, s);
-    else if (nvec <= 32) launch_seg<32, 1, 4, W, RS>(a, s);
-    else if (nvec <= 64) launch_seg<64, 1, 8, W, RS>(a, s);
-    else if (nvec <= 128) launch_seg<64, 2, 4, W, RS>(a, s);
-    else launch_seg<64, 4, 2, W, RS>(a, s);
+    if (nvec <= 4) launch_seg<4, 1, 4, W, RS, TAG>(a, s);
+    else if (nvec <= 8) launch_seg<8, 1, 4, W, RS, TAG>(a, s);
+    else if (nvec <= 16) launch_seg<16, 1, 4, W, RS, TAG>(a, s);
+    else if (nvec <= 32) launch_seg<32, 1, 4, W, RS, TAG>(a, s);
+    else if (nvec <= 64) {
+        if (!W && !RS) launch_seg_tuned<TAG>(a, s);
+        else launch_seg<64, 1, 8, W, RS, TAG>(a, s);
+    } else if (nvec <= 128) launch_seg<64, 2, 4, W, RS, TAG>(a, s);
+    else launch_seg<64, 4, 2, W, RS, TAG>(a, s);
     return HGNN_OK;
 }
 
@@ -370,6 +410,9 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     HGNN_REQUIRE(name != nullptr, "hgnn_set_option: name is NULL");
     if (!strcmp(name, "nt_loads")) g_opt_nt_loads = value;
     else if (!strcmp(name, "nt_stores")) g_opt_nt_stores = value;
+    else if (!strcmp(name, "seg_unroll")) g_opt_seg_unroll = value;
+    else if (!strcmp(name, "seg_wpb")) g_opt_seg_wpb = value;
+    else if (!strcmp(name, "seg_xcd")) g_opt_seg_xcd = value;
     else {
         set_error("hgnn_set_option: unknown option '%s'", name);
         return HGNN_ERR_INVALID_ARG;
@@ -404,12 +447,12 @@ extern "C" int hgnn_segment_reduce_f32(const hgnn_plan* plan, const float* src, 
     a.out = out;
     a.partial = partial;
     int rc;
-    if (weight && row_scale) rc = dispatch_seg<true, true>(a, stream);
-    else if (weight) rc = dispatch_seg<true, false>(a, stream);
+    if (weight && row_scale) rc = dispatch_seg<true, true, 0>(a, stream);
+    else if (weight) rc = dispatch_seg<true, false, 0>(a, stream);
     else if (row_scale) {
         set_error("hgnn_segment_reduce_f32: row_scale requires weight");
         return HGNN_ERR_UNSUPPORTED;
-    } else rc = dispatch_seg<false, false>(a, stream);
+    } else rc = dispatch_seg<false, false, 0>(a, stream);
     if (rc != HGNN_OK) return rc;
     // second pass: sum the partial rows of split destinations, in chunk order
     SegArgs b;
@@ -426,7 +469,7 @@ extern "C" int hgnn_segment_reduce_f32(const hgnn_plan* plan, const float* src, 
     b.max_items = plan->max_split;
     b.out = out;
     b.partial = partial;
-    rc = dispatch_seg<false, false>(b, stream);
+    rc = dispatch_seg<false, false, 1>(b, stream);
     if (rc != HGNN_OK) return rc;
     HGNN_CHECK_HIP(hipGetLastError());
     return HGNN_OK;
