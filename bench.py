@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--latent", type=int, default=LATENT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--halo-mode", default="all_gather", choices=["all_gather", "all_to_all"])
     ap.add_argument("--extra", action="store_true", help="also time K2-K6 and a full cell (stderr)")
     return ap.parse_args()
 
@@ -92,6 +93,7 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -102,7 +104,11 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("HGNN_BENCH_BACKEND", "nccl")  # "gloo": 2-rank rehearsal on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     L = args.latent
     halo = None
@@ -118,7 +124,7 @@ def main():
         shard = partition.partition_event(x, ei, world, rank)
         graph = shard.local_graph.to(device)
         n_local = shard.n_owned
-        halo = partition.HaloExchange(shard, device)
+        halo = partition.HaloExchange(shard, device, mode=args.halo_mode)
         dst_cpu = None
     M = int(graph.shape[1])
     gen = torch.Generator(device=device).manual_seed(1235 + rank)
@@ -195,7 +201,9 @@ def main():
                 "workload": wl,
                 "rows_per_gpu": M,
                 "dst_rows_per_gpu": n_local,
-                "partition": "single event" if world == 1 else f"phi-wedge node partition x{world}, halo exchange on side stream",
+                "partition": "single event" if world == 1 else
+                f"phi-wedge node partition x{world}; per step: local K1 + {args.halo_mode} halo exchange of "
+                f"{halo.shard.n_halo} boundary rows x {L} f32 on a side stream (rank 0)",
                 "plan_build_ms": plan_ms,
                 "plan_chunk": plan.chunk,
             },

@@ -1,0 +1,263 @@
+"""Node-partitioned events across the GPUs of one node, with a halo exchange per cell.
+
+The reference is single-GPU (Notebooks/script.py:35, README.md:65); this module is
+the MI355X-side design SURVEY.md section 8e describes, with no reference counterpart:
+
+  * hits are ordered by phi and cut into ``P`` contiguous wedges balanced on
+    in-degree (work is proportional to the rows a rank aggregates, not to its hits);
+  * a directed edge (u -> v) belongs to ``owner(v)``: the K1 aggregation
+    (Modules/gnn_utils.py:50) is purely local and needs no communication;
+  * only the edge update (gnn_utils.py:61) reads remote data -- ``nodes[u]`` of
+    cut edges -- so each cell has exactly one exchange step: after the node
+    update every rank sends the rows of its boundary hits to the ranks that
+    own an edge leaving them (RCCL over xGMI; point-to-point grouped send/recv
+    = ``all_to_all_single`` with ragged splits, or a padded ``all_gather`` of
+    the boundary blocks -- ``mode``);
+  * HGNN supernodes / superedges are small ([S,L] ~ 10 MB) and stay replicated;
+    the node->supernode sums (K3/K5) are computed on the owned hits and combined
+    with one ``all_reduce``.
+
+Everything here is index bookkeeping plus ``torch.distributed`` calls, so it runs
+unchanged under the ``gloo`` backend on CPU tensors (tests/test_partition_gloo.py);
+on the GPU the pack/unpack gathers go through the HIP row-gather kernel.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+
+@dataclass
+class EventShard:
+    rank: int
+    world: int
+    n_global: int
+    n_owned: int
+    n_halo: int
+    owned_global: torch.Tensor      # [n_owned]  global hit id of local row i
+    halo_global: torch.Tensor       # [n_halo]   global hit id of halo row n_owned + j (grouped by owner)
+    local_graph: torch.Tensor       # [2, M_p]   row 0: local source id (owned or halo), row 1: owned destination
+    edge_global: torch.Tensor       # [M_p]      column of the global DIRECTED graph each local edge is
+    send_index: torch.Tensor        # [sum(send_splits)] owned local ids, grouped by destination rank
+    send_splits: List[int] = field(default_factory=list)
+    recv_splits: List[int] = field(default_factory=list)
+
+
+def node_owner(x: torch.Tensor, directed_graph: torch.Tensor, world: int):
+    """phi-ordered contiguous wedges, balanced on in-degree.  Returns (owner[N], pos[N])."""
+    n = x.shape[0]
+    order = torch.argsort(x[:, 1], stable=True)
+    pos = torch.empty(n, dtype=torch.long)
+    pos[order] = torch.arange(n)
+    deg = torch.bincount(directed_graph[1], minlength=n).double() + 1e-3  # hits without edges still cost a row
+    cum = torch.cumsum(deg[order], 0)
+    total = float(cum[-1]) if n else 0.0
+    bounds = torch.tensor([total * k / world for k in range(1, world)], dtype=torch.double)
+    cuts = torch.searchsorted(cum, bounds).tolist() if n else []
+    owner_sorted = torch.zeros(n, dtype=torch.long)
+    prev = 0
+    for r, c in enumerate(cuts + [n]):
+        owner_sorted[prev:c] = r
+        prev = max(prev, c)
+    owner = torch.empty(n, dtype=torch.long)
+    owner[order] = owner_sorted
+    return owner, pos
+
+
+def partition_event(x: torch.Tensor, edge_index: torch.Tensor, world: int, rank: int,
+                    already_directed: bool = False) -> EventShard:
+    """Shard one event (CPU tensors).  ``edge_index`` is the stored [2,E] graph; it is
+    doubled exactly as the model does (EdgeClassifier/Models/IN.py:122) unless
+    ``already_directed``.  Deterministic: every rank derives the same partition."""
+    graph = edge_index if already_directed else torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    n = x.shape[0]
+    owner, pos = node_owner(x, graph, world)
+    src, dst = graph[0], graph[1]
+    mine = owner[dst] == rank
+    edge_global = torch.nonzero(mine).squeeze(1)
+    e_src, e_dst = src[edge_global], dst[edge_global]
+
+    owned_global = torch.nonzero(owner == rank).squeeze(1)
+    owned_global = owned_global[torch.argsort(pos[owned_global])]          # phi order inside the wedge
+    n_owned = owned_global.numel()
+    g2l = torch.full((n,), -1, dtype=torch.long)
+    g2l[owned_global] = torch.arange(n_owned)
+
+    # halo: remote sources of my edges, grouped by owner, phi-ordered inside a group
+    src_owner = owner[e_src]
+    recv_splits, halo_parts = [], []
+    for a in range(world):
+        if a == rank:
+            recv_splits.append(0)
+            continue
+        nodes = torch.unique(e_src[src_owner == a])
+        nodes = nodes[torch.argsort(pos[nodes])]
+        halo_parts.append(nodes)
+        recv_splits.append(int(nodes.numel()))
+    halo_global = torch.cat(halo_parts) if halo_parts else torch.zeros(0, dtype=torch.long)
+    g2l[halo_global] = n_owned + torch.arange(halo_global.numel())
+
+    # what I must send: my hits that are sources of edges owned by q (same order as q's halo group)
+    dst_owner_all = owner[dst]
+    src_owner_all = owner[src]
+    send_splits, send_parts = [], []
+    for q in range(world):
+        if q == rank:
+            send_splits.append(0)
+            continue
+        nodes = torch.unique(src[(src_owner_all == rank) & (dst_owner_all == q)])
+        nodes = nodes[torch.argsort(pos[nodes])]
+        send_parts.append(g2l[nodes])
+        send_splits.append(int(nodes.numel()))
+    send_index = torch.cat(send_parts) if send_parts else torch.zeros(0, dtype=torch.long)
+
+    local_graph = torch.stack([g2l[e_src], g2l[e_dst]]).contiguous()
+    assert int(local_graph.min()) >= 0 if local_graph.numel() else True
+    return EventShard(rank=rank, world=world, n_global=n, n_owned=n_owned, n_halo=int(halo_global.numel()),
+                      owned_global=owned_global, halo_global=halo_global, local_graph=local_graph,
+                      edge_global=edge_global, send_index=send_index.contiguous(),
+                      send_splits=send_splits, recv_splits=recv_splits)
+
+
+def _pack(rows: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    if rows.is_cuda:
+        from .ops import gather_rows
+        return gather_rows(rows, index)
+    return rows.index_select(0, index)       # gloo / CPU rehearsal of the same data path
+
+
+class _A2A(torch.autograd.Function):
+    """ragged all-to-all of packed rows; backward is the reverse all-to-all"""
+
+    @staticmethod
+    def forward(ctx, send, send_splits, recv_splits, group):
+        import torch.distributed as dist
+        ctx.splits = (send_splits, recv_splits)
+        ctx.group = group
+        recv = send.new_empty((sum(recv_splits),) + tuple(send.shape[1:]))
+        dist.all_to_all_single(recv, send.contiguous(), recv_splits, send_splits, group=group)
+        return recv
+
+    @staticmethod
+    def backward(ctx, grad_recv):
+        import torch.distributed as dist
+        send_splits, recv_splits = ctx.splits
+        grad_send = grad_recv.new_empty((sum(send_splits),) + tuple(grad_recv.shape[1:]))
+        dist.all_to_all_single(grad_send, grad_recv.contiguous(), send_splits, recv_splits, group=ctx.group)
+        return grad_send, None, None, None
+
+
+class _AllGatherBlocks(torch.autograd.Function):
+    """padded all_gather of every rank's boundary block; backward = reduce_scatter (sum)"""
+
+    @staticmethod
+    def forward(ctx, block, group):
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        ctx.group = group
+        out = block.new_empty((world * block.shape[0],) + tuple(block.shape[1:]))
+        dist.all_gather_into_tensor(out, block.contiguous(), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        import torch.distributed as dist
+        world = dist.get_world_size(ctx.group)
+        grad_block = grad_out.new_empty((grad_out.shape[0] // world,) + tuple(grad_out.shape[1:]))
+        g = grad_out.contiguous()
+        if g.is_cuda:
+            dist.reduce_scatter_tensor(grad_block, g, group=ctx.group)
+        else:  # gloo has no reduce_scatter: all_reduce then slice
+            dist.all_reduce(g, group=ctx.group)
+            r = dist.get_rank(ctx.group)
+            grad_block = g[r * grad_block.shape[0]:(r + 1) * grad_block.shape[0]].clone()
+        return grad_block, None
+
+
+class HaloExchange:
+    """One exchange step of a cell: ``extend(nodes_owned) -> [n_owned + n_halo, L]``.
+
+    mode "all_to_all": each rank receives exactly the rows it reads (grouped send/recv,
+                       one message per neighbour pair; phi-wedges make most pairs empty).
+    mode "all_gather": every rank contributes its padded boundary block and gathers
+                       all of them (one collective, more bytes); the halo is then a
+                       row gather out of the gathered buffer.
+    Differentiable: gradients of halo rows flow back to their owners.
+    """
+
+    def __init__(self, shard: EventShard, device=None, mode: str = "all_to_all", group=None):
+        import torch.distributed as dist
+        self.shard = shard
+        self.mode = mode
+        self.group = group
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.send_index = shard.send_index.to(self.device)
+        self.send_splits = list(shard.send_splits)
+        self.recv_splits = list(shard.recv_splits)
+        if mode == "all_gather":
+            # boundary block = my hits any peer needs (deduplicated), padded to the global max
+            boundary = torch.unique(shard.send_index)
+            t = torch.tensor([boundary.numel()], dtype=torch.long, device=self.device)
+            sizes = [torch.zeros_like(t) for _ in range(shard.world)]
+            dist.all_gather(sizes, t, group=group)
+            self.block = max(1, max(int(s_.item()) for s_ in sizes))
+            pad = torch.zeros(self.block - boundary.numel(), dtype=torch.long)
+            self.boundary_index = torch.cat([boundary, pad]).to(self.device)
+            # where, in the gathered [world*block] buffer, does each of my halo rows sit?
+            # every rank needs the boundary lists of its peers: exchange them once.
+            mine = torch.full((self.block,), -1, dtype=torch.long)
+            mine[:boundary.numel()] = shard.owned_global[boundary]
+            lists = [torch.empty(self.block, dtype=torch.long, device=self.device) for _ in range(shard.world)]
+            dist.all_gather(lists, mine.to(self.device), group=group)
+            flat = torch.cat([l.cpu() for l in lists])
+            lookup = {int(g): i for i, g in enumerate(flat.tolist()) if g >= 0}
+            self.halo_from_gathered = torch.tensor([lookup[int(g)] for g in shard.halo_global.tolist()],
+                                                   dtype=torch.long, device=self.device)
+        elif mode != "all_to_all":
+            raise ValueError(mode)
+
+    def exchange(self, nodes_owned: torch.Tensor) -> torch.Tensor:
+        """rows of the remote sources of my edges, [n_halo, L]"""
+        if self.mode == "all_to_all":
+            send = _pack(nodes_owned, self.send_index)
+            return _A2A.apply(send, self.send_splits, self.recv_splits, self.group)
+        block = _pack(nodes_owned, self.boundary_index)
+        gathered = _AllGatherBlocks.apply(block, self.group)
+        return _pack(gathered, self.halo_from_gathered)
+
+    def extend(self, nodes_owned: torch.Tensor) -> torch.Tensor:
+        return torch.cat([nodes_owned, self.exchange(nodes_owned)], dim=0)
+
+    def halo_bytes(self, latent: int) -> int:
+        return 4 * latent * self.shard.n_halo
+
+
+def distributed_cell_forward(cell, halo: HaloExchange, nodes_owned, edges_local, local_graph):
+    """InteractionGNNCell.forward (Modules/gnn_utils.py:66-71) on one shard:
+    local aggregation + node MLP, ONE halo exchange, then the edge update."""
+    nodes_owned = cell.node_update(nodes_owned, edges_local, local_graph)
+    nodes_ext = halo.extend(nodes_owned)
+    edges_local = cell.edge_update(nodes_ext, edges_local, local_graph)
+    return nodes_owned, edges_local
+
+
+def allreduce_supernode_sums(partial: torch.Tensor, group=None) -> torch.Tensor:
+    """K3/K5 across shards: each rank sums its owned hits into the replicated [S,L]
+    supernode table; one all_reduce combines them."""
+    import torch.distributed as dist
+
+    class _AR(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            out = t.clone()
+            dist.all_reduce(out, group=group)
+            return out
+
+        @staticmethod
+        def backward(ctx, g):
+            # every rank holds the same downstream gradient of the replicated sum
+            return g
+
+    return _AR.apply(partial)

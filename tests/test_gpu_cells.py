@@ -76,3 +76,42 @@ def test_bc_hgnn_cell_loop_from_reference_forward():
             outs = cell(*args)
         for nm, o in zip(names[:4], outs):
             assert rel_err(o.cpu().numpy(), z[f"cell{i}.out.{nm}"]) <= TOL, (i, nm)
+
+
+def test_ec_in_full_forward_config1_shape():
+    """BASELINE config 1/2 model: EC-IN forward(x, edge_index) with the reference's
+    state_dict reproduces the reference's scores (latent=32, 14 cells, 286,977 params)."""
+    from hierarchicalgnn_amd.models import EC_InteractionGNN
+    z = load_golden("ec_in_L32.npz")
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    model = EC_InteractionGNN(hp)
+    assert sum(p.numel() for p in model.parameters()) == int(z["n_params"]) == 286977
+    model = _load(model, z)
+    x = torch.from_numpy(z["x"]).cuda()
+    graph = torch.from_numpy(z["edge_index"]).cuda()
+    with torch.no_grad():
+        scores = model(x, graph)
+    assert scores.shape == z["scores"].shape
+    assert np.abs(scores.cpu().numpy() - z["scores"]).max() <= 1e-4
+    # training-mode call: reentrant checkpointing + autograd through every HIP op
+    scores = model(x, graph)
+    scores.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_torch_scatter_shim_resolves_to_hip():
+    import importlib
+    import sys
+    import conftest
+    sys.path.insert(0, conftest.ROOT + "/torch_scatter_shim")
+    try:
+        ts = importlib.import_module("torch_scatter")
+        src = torch.randn(100, 8).cuda()
+        idx = torch.randint(0, 9, (100,)).cuda()
+        ref = torch.zeros(9, 8).index_add_(0, idx.cpu(), src.cpu())
+        assert rel_err(ts.scatter_add(src, idx, dim=0, dim_size=9).cpu().numpy(), ref.numpy()) <= TOL
+        cnt = torch.bincount(idx.cpu(), minlength=9).clamp(min=1).float().unsqueeze(1)
+        assert rel_err(ts.scatter_mean(src, idx, dim=0, dim_size=9).cpu().numpy(), (ref / cnt).numpy()) <= TOL
+    finally:
+        sys.path.pop(0)
+        sys.modules.pop("torch_scatter", None)

@@ -1,0 +1,137 @@
+"""world_size-2 (and 3) rehearsal of the multi-GPU path on CPU with the gloo backend:
+node partition + one halo exchange per cell reproduce the single-process result.
+The arithmetic inside each rank is the CPU oracle here (the HIP kernels need a GPU);
+what is under test is the partition bookkeeping, the exchange and its backward."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import conftest  # noqa: F401  (sys.path)
+from hierarchicalgnn_amd import partition, synth
+from oracle import hgnn_oracle as O
+
+HP = dict(latent=16, hidden=32, nb_edge_layer=2, nb_node_layer=3, layernorm=True, hidden_activation="GELU")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_problem():
+    from hierarchicalgnn_amd import InteractionGNNCell
+    torch.manual_seed(0)
+    x, ei = synth.trackml_event(600, 3000, seed=3)
+    graph = synth.directed(ei)
+    cell = InteractionGNNCell(HP)
+    sd = {k: v.detach().clone() for k, v in cell.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    nodes = torch.randn(600, 16, generator=g)
+    edges = torch.randn(graph.shape[1], 16, generator=g)
+    r_n = torch.randn(600, 16, generator=g)
+    r_e = torch.randn(graph.shape[1], 16, generator=g)
+    return x, ei, graph, sd, nodes, edges, r_n, r_e
+
+
+class _OracleCell:
+    """stands in for the HIP cell on CPU: same two-phase interface"""
+
+    def __init__(self, sd):
+        self.sd = sd
+
+    def node_update(self, nodes, edges, graph):
+        return O.ignn_node_update(self.sd, "", HP, nodes, edges, graph)
+
+    def edge_update(self, nodes, edges, graph):
+        return O.edge_update(self.sd, "", HP, nodes, edges, graph)
+
+
+def _worker(rank, world, port, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        x, ei, graph, sd, nodes, edges, r_n, r_e = _make_problem()
+        shard = partition.partition_event(x, ei, world, rank)
+        halo = partition.HaloExchange(shard, "cpu", mode=mode)
+        n_loc = nodes[shard.owned_global].clone().requires_grad_(True)
+        e_loc = edges[shard.edge_global].clone().requires_grad_(True)
+        out_n, out_e = partition.distributed_cell_forward(_OracleCell(sd), halo, n_loc, e_loc, shard.local_graph)
+        loss = (out_n * r_n[shard.owned_global]).sum() + (out_e * r_e[shard.edge_global]).sum()
+        loss.backward()
+        # K3 across shards: owned hits -> replicated supernodes, one all_reduce
+        bg, bw = synth.bipartite_assignment(600, 13, 3, seed=5)
+        own = torch.zeros(600, dtype=torch.bool)
+        own[shard.owned_global] = True
+        sel = own[bg[0]]
+        part = O.scatter_add(bw[sel] * nodes[bg[0][sel]], bg[1][sel], 0, 13)
+        pooled = partition.allreduce_supernode_sums(part)
+        q.put((rank, shard.owned_global, shard.edge_global, out_n.detach(), out_e.detach(),
+               n_loc.grad.clone(), e_loc.grad.clone(), pooled, shard.n_halo, shard.send_splits, shard.recv_splits))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "all_to_all"), (2, "all_gather"), (3, "all_to_all")])
+def test_partitioned_cell_matches_single_process(world, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    x, ei, graph, sd, nodes, edges, r_n, r_e = _make_problem()
+    n_ref = nodes.clone().requires_grad_(True)
+    e_ref = edges.clone().requires_grad_(True)
+    on, oe = O.ignn_cell(sd, "", HP, n_ref, e_ref, graph)
+    ((on * r_n).sum() + (oe * r_e).sum()).backward()
+    bg, bw = synth.bipartite_assignment(600, 13, 3, seed=5)
+    pooled_ref = O.scatter_add(bw * nodes[bg[0]], bg[1], 0, 13)
+
+    seen_nodes = torch.zeros(600, dtype=torch.long)
+    seen_edges = torch.zeros(graph.shape[1], dtype=torch.long)
+    for rank, owned, eglob, out_n, out_e, gn, ge, pooled, n_halo, ss, rs in results:
+        seen_nodes[owned] += 1
+        seen_edges[eglob] += 1
+        assert torch.allclose(out_n, on.detach()[owned], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(out_e, oe.detach()[eglob], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(ge, e_ref.grad[eglob], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(gn, n_ref.grad[owned], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(pooled, pooled_ref, rtol=1e-5, atol=1e-5)
+        assert n_halo == sum(rs) and n_halo > 0
+    # every hit and every directed edge is owned exactly once
+    assert int(seen_nodes.min()) == 1 and int(seen_nodes.max()) == 1
+    assert int(seen_edges.min()) == 1 and int(seen_edges.max()) == 1
+    # what r sends to q is what q receives from r
+    by_rank = {r[0]: r for r in results}
+    for a in range(world):
+        for b in range(world):
+            assert by_rank[a][9][b] == by_rank[b][10][a]
+
+
+def test_partition_is_balanced_and_local():
+    x, ei = synth.trackml_event(20_000, 160_000, seed=7)
+    rows = []
+    for r in range(4):
+        s = partition.partition_event(x, ei, 4, r)
+        rows.append(s.local_graph.shape[1])
+        assert int(s.local_graph[1].max()) < s.n_owned          # destinations are owned
+        assert int(s.local_graph[0].max()) < s.n_owned + s.n_halo
+        # phi-wedges: the halo is a small fraction of the owned hits' sources
+        assert s.n_halo < 0.5 * s.n_owned
+    assert max(rows) / (sum(rows) / 4) < 1.05                    # edge-balanced
+    assert sum(rows) == 2 * ei.shape[1]
