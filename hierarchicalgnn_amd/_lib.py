@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID = 0, 1, 2, 3, 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HgnnPlan(Structure):
@@ -49,6 +49,8 @@ _SIGNATURES = {
     "hgnn_abi_version": (c_int, []),
     "hgnn_last_error": (c_char_p, []),
     "hgnn_set_option": (c_int, [c_char_p, c_int]),
+    "hgnn_sizeof_plan": (c_int, []),
+    "hgnn_sizeof_mlp_desc": (c_int, []),
     "hgnn_plan_dims": (c_int, [c_int64, c_int64, c_int64, c_int32, POINTER(HgnnPlan)]),
     "hgnn_plan_workspace_bytes": (c_int, [c_int64, c_int64, POINTER(c_size_t)]),
     "hgnn_plan_build": (c_int, [c_void_p, c_void_p, POINTER(HgnnPlan), c_void_p, c_size_t, c_void_p]),
@@ -59,6 +61,8 @@ _SIGNATURES = {
     "hgnn_edge_dot_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                   c_int64, c_void_p, c_void_p]),
     "hgnn_index_to_i32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "hgnn_mlp_supported": (c_int, [POINTER(HgnnMlpDesc)]),
+    "hgnn_mlp_forward_f32": (c_int, [POINTER(HgnnMlpDesc), c_void_p, c_void_p]),
 }
 
 _lib = None

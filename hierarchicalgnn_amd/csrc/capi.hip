@@ -15,3 +15,5 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int hgnn_abi_version(void) { return HGNN_ABI_VERSION; }
 extern "C" const char* hgnn_last_error(void) { return hgnn::g_err; }
+extern "C" int hgnn_sizeof_plan(void) { return (int)sizeof(hgnn_plan); }
+extern "C" int hgnn_sizeof_mlp_desc(void) { return (int)sizeof(hgnn_mlp_desc); }

@@ -1,0 +1,352 @@
+// Fused  gather -> concat -> [Linear -> LayerNorm -> act] x {2,3} -> (+skip)  on fp32 MFMA.
+//
+// Replaces, for one make_mlp Sequential (reference Modules/utils.py:169-196) and the
+// concat/gather feeding it (Modules/gnn_utils.py:52-53, :61-62, :126, :134, :144, :152):
+//     cat([nodes[g0], nodes[g1], edges]) -> Linear -> LN -> GELU -> Linear -> LN -> Tanh -> + edges
+// without ever writing the [M,3L] concat, the gathered copies or the [M,H] hidden
+// activations to HBM (>= 16 GB of avoidable traffic per cell at L=256, M=2M).
+//
+// Mapping (wave64, v_mfma_f32_16x16x4_f32, exact fp32 = fmaf chain):
+//   * the GEMMs are evaluated TRANSPOSED:  D[f][e] = sum_k W[f][k] * X[e][k]
+//     A operand = weight fragment, B operand = activations.  The D layout then
+//     puts the edge on the lane (col = lane&15) and the features in registers
+//     (row = 4*(lane>>4) + reg), so
+//       - LayerNorm statistics over features are in-register sums plus two
+//         cross-lane adds (no LDS, no cross-wave traffic);
+//       - the activated accumulator tile of layer i IS the B operand of layer
+//         i+1 (regs r=0..3 of tile c hold k = 16c + 4*(lane>>4) + r, exactly the
+//         four k-steps of that tile) -- hidden activations never leave registers.
+//   * one wave owns 16 edges and ALL features of every layer; a workgroup is 4
+//     waves = 64 edges.  Weights stream through LDS in k-chunks of 16
+//     (A-fragment order, filled by LDS-DMA global_load_lds_dwordx4, double
+//     buffered, one barrier per chunk); the activations X are read straight from
+//     global memory into the B-operand layout (16 rows x 64 B per wave load),
+//     with the row gather folded into the per-lane address.
+//   * 2 workgroups per CU (<=256 VGPRs) so that one block's LayerNorm/GELU
+//     epilogue (VALU) overlaps the other's MFMAs; the 3-layer L=256 node
+//     network needs 320 accumulator registers and runs at 1 workgroup per CU.
+#include "common.h"
+
+namespace hgnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpArgs {
+    const float* seg_table[3];
+    const int32_t* seg_index[3];
+    int seg_width[3];
+    int n_seg;
+    int K1;
+    const float* W[3];
+    const float* b[3];
+    const float* lnw[3];
+    const float* lnb[3];
+    int act[3];
+    float eps;
+    const float* skip;
+    float* out;
+    long long M;
+};
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    switch (act) {
+        case HGNN_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        case HGNN_ACT_TANH: return tanhf(x);
+        case HGNN_ACT_RELU: return x > 0.f ? x : 0.f;
+        default: return x;
+    }
+}
+
+// stage rows [0, NF) x columns [k0, k0+16) of W[NF][Kdim] into lds, one 1-KiB piece per 16 rows,
+// each piece in A-fragment order [g = k/4][i = row][4 floats]
+template <int NF>
+__device__ __forceinline__ void stage_w(const float* __restrict__ W, int Kdim, int k0, float* lds,
+                                        int wave, int lane) {
+    constexpr int PIECES = NF / 16;  // 1 KiB each
+    constexpr int PER_WAVE = (PIECES + 3) / 4;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int p = i * 4 + wave;  // wave is wave-uniform (SGPR): a scalar branch, no exec masking
+        if (PIECES % 4 != 0 && p >= PIECES) break;
+        // lane (i = lane&15, g = lane>>4) fetches W[16p+i][k0+4g .. +3]; the DMA lands it at
+        // lane*16 bytes, i.e. the piece is stored in exactly the order the MFMA A-fragment read
+        // (ds_read_b128 at lane*16) wants: conflict-free, no swizzle needed.
+        const float* src = W + (size_t)(p * 16 + (lane & 15)) * (size_t)Kdim + k0 + (lane >> 4) * 4;
+        float* dst = lds + p * 256;  // wave-uniform base; the DMA adds lane*16 bytes
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+// acc[T][r] (edge = lane&15, feature = 16T + 4*(lane>>4) + r): LayerNorm over features, then act
+template <int NT>
+__device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT], const float* __restrict__ lnw,
+                                              const float* __restrict__ lnb, int act, float eps, int g) {
+    constexpr float inv_n = 1.0f / (float)(NT * 16);
+    float s = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT; ++T) s += (acc[T].x + acc[T].y) + (acc[T].z + acc[T].w);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float mean = s * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        f32x4 d = acc[T] - mean;
+        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    const float rstd = 1.0f / sqrtf(q * inv_n + eps);
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        const f32x4 w4 = *(const f32x4*)(lnw + T * 16 + g * 4);
+        const f32x4 b4 = *(const f32x4*)(lnb + T * 16 + g * 4);
+        f32x4 v = (acc[T] - mean) * rstd * w4 + b4;
+        v.x = act_apply(v.x, act);
+        v.y = act_apply(v.y, act);
+        v.z = act_apply(v.z, act);
+        v.w = act_apply(v.w, act);
+        acc[T] = v;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void init_bias(f32x4 (&acc)[NT], const float* __restrict__ b, int g) {
+#pragma unroll
+    for (int T = 0; T < NT; ++T) acc[T] = *(const f32x4*)(b + T * 16 + g * 4);
+}
+
+// one register-resident layer: out[NTO tiles] = W[NTO*16][NTI*16] * in  (in = previous accumulators)
+template <int NTI, int NTO>
+__device__ __forceinline__ void dense_from_regs(const f32x4 (&in)[NTI], f32x4 (&out)[NTO],
+                                                const float* __restrict__ W, float* lds, int wave, int lane) {
+    constexpr int KD = NTI * 16;
+    constexpr int BUF = NTO * 256;  // floats per chunk buffer
+    __syncthreads();                // everyone is done with both buffers of the previous layer
+    stage_w<NTO * 16>(W, KD, 0, lds, wave, lane);
+#pragma unroll
+    for (int c = 0; c < NTI; ++c) {
+        __syncthreads();  // chunk c landed (vmcnt(0) precedes the barrier); buffer (c+1)&1 is free
+        if (c + 1 < NTI) stage_w<NTO * 16>(W, KD, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
+        const float* wb = lds + (c & 1) * BUF + lane * 4;
+        f32x4 a = *(const f32x4*)wb;
+#pragma unroll
+        for (int T = 0; T < NTO; ++T) {
+            // fetch the next tile's weight fragment before this tile's MFMAs (hides the LDS latency)
+            const f32x4 an = *(const f32x4*)(wb + (T + 1 < NTO ? T + 1 : T) * 256);
+            out[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, in[c].x, out[T], 0, 0, 0);
+            out[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, in[c].y, out[T], 0, 0, 0);
+            out[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, in[c].z, out[T], 0, 0, 0);
+            out[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, in[c].w, out[T], 0, 0, 0);
+            a = an;
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void store_out(const f32x4 (&acc)[NT], const MlpArgs& a, long long e, bool valid,
+                                          int g) {
+    if (!valid) return;
+    constexpr int NOUT = NT * 16;
+    float* op = a.out + (size_t)e * NOUT + g * 4;
+    if (a.skip != nullptr) {
+        const float* sp = a.skip + (size_t)e * NOUT + g * 4;
+#pragma unroll
+        for (int T = 0; T < NT; ++T) *(f32x4*)(op + T * 16) = acc[T] + *(const f32x4*)(sp + T * 16);
+    } else {
+#pragma unroll
+        for (int T = 0; T < NT; ++T) *(f32x4*)(op + T * 16) = acc[T];
+    }
+}
+
+// NT1/NT2/NT3: 16-feature tiles of layer 1 / 2 / 3 outputs (NT3 == 0: two-layer MLP)
+template <int NT1, int NT2, int NT3, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ei = lane & 15;
+    const int g = lane >> 4;
+    const long long e = (long long)blockIdx.x * 64 + wave * 16 + ei;
+    const bool valid = e < a.M;
+    const long long er = valid ? e : 0;
+
+    // per-lane row start of every input segment (the gather is folded in here).  The X stream is
+    // read through ONE running pointer that hops to the next segment's row at a segment boundary,
+    // so nothing is runtime-indexed (cdna_hip_programming.md 5.4 rule 20).
+    const float* q0;
+    const float* q1;
+    const float* q2;
+    {
+        long long r = a.seg_index[0] != nullptr ? (long long)a.seg_index[0][er] : er;
+        q0 = a.seg_table[0] + (size_t)(r < 0 ? 0 : r) * (size_t)a.seg_width[0] + g * 4;
+        q1 = q0;
+        q2 = q0;
+        if (a.n_seg > 1) {
+            r = a.seg_index[1] != nullptr ? (long long)a.seg_index[1][er] : er;
+            q1 = a.seg_table[1] + (size_t)(r < 0 ? 0 : r) * (size_t)a.seg_width[1] + g * 4;
+        }
+        if (a.n_seg > 2) {
+            r = a.seg_index[2] != nullptr ? (long long)a.seg_index[2][er] : er;
+            q2 = a.seg_table[2] + (size_t)(r < 0 ? 0 : r) * (size_t)a.seg_width[2] + g * 4;
+        }
+    }
+    const int nc = a.K1 / 16;
+    const int c1 = a.seg_width[0] / 16;                       // first chunk of segment 1
+    const int c2 = c1 + (a.n_seg > 1 ? a.seg_width[1] / 16 : nc);  // first chunk of segment 2
+    const float* px = q0;
+    int cl = 0;  // next chunk the X stream will load
+    auto next_x = [&](f32x4 fallback) -> f32x4 {
+        f32x4 v = fallback;
+        if (cl < nc) v = *(const f32x4*)px;
+        ++cl;
+        px += 16;
+        if (cl == c1) px = q1;
+        if (cl == c2) px = q2;
+        return v;
+    };
+
+    // ---------------- layer 1: K1 (runtime) -> NT1*16, weights through LDS, X from global
+    f32x4 acc1[NT1];
+    init_bias<NT1>(acc1, a.b[0], g);
+    {
+        constexpr int BUF = NT1 * 256;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        stage_w<NT1 * 16>(a.W[0], a.K1, 0, lds, wave, lane);
+        f32x4 x0 = next_x(zero);
+        f32x4 x1 = next_x(zero);
+        for (int c = 0; c < nc; ++c) {
+            __syncthreads();
+            if (c + 1 < nc) stage_w<NT1 * 16>(a.W[0], a.K1, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
+            const f32x4 x2 = next_x(zero);
+            const float* wb = lds + (c & 1) * BUF + lane * 4;
+            f32x4 w = *(const f32x4*)wb;
+#pragma unroll
+            for (int T = 0; T < NT1; ++T) {
+                const f32x4 wn = *(const f32x4*)(wb + (T + 1 < NT1 ? T + 1 : T) * 256);
+                acc1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x0.x, acc1[T], 0, 0, 0);
+                acc1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x0.y, acc1[T], 0, 0, 0);
+                acc1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x0.z, acc1[T], 0, 0, 0);
+                acc1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x0.w, acc1[T], 0, 0, 0);
+                w = wn;
+            }
+            x0 = x1;
+            x1 = x2;
+        }
+    }
+    layernorm_act<NT1>(acc1, a.lnw[0], a.lnb[0], a.act[0], a.eps, g);
+
+    // ---------------- layer 2 (and 3): activations stay in registers
+    f32x4 acc2[NT2];
+    init_bias<NT2>(acc2, a.b[1], g);
+    dense_from_regs<NT1, NT2>(acc1, acc2, a.W[1], lds, wave, lane);
+    layernorm_act<NT2>(acc2, a.lnw[1], a.lnb[1], a.act[1], a.eps, g);
+    if constexpr (NT3 == 0) {
+        store_out<NT2>(acc2, a, e, valid, g);
+    } else {
+        f32x4 acc3[NT3];
+        init_bias<NT3>(acc3, a.b[2], g);
+        dense_from_regs<NT2, NT3>(acc2, acc3, a.W[2], lds, wave, lane);
+        layernorm_act<NT3>(acc3, a.lnw[2], a.lnb[2], a.act[2], a.eps, g);
+        store_out<NT3>(acc3, a, e, valid, g);
+    }
+}
+
+template <int NT1, int NT2, int NT3, int MINW>
+static int launch_mlp(const MlpArgs& a, hipStream_t s) {
+    constexpr int maxnt = NT1 > NT2 ? (NT1 > NT3 ? NT1 : NT3) : (NT2 > NT3 ? NT2 : NT3);
+    const size_t lds_bytes = (size_t)2 * maxnt * 256 * sizeof(float);
+    const unsigned grid = (unsigned)ceil_div(a.M, 64);
+    auto kern = k_fused_mlp<NT1, NT2, NT3, MINW>;
+    if (lds_bytes > 64 * 1024) {
+        HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes));
+    }
+    kern<<<grid, 256, lds_bytes, s>>>(a);
+    HGNN_CHECK_HIP(hipGetLastError());
+    return HGNN_OK;
+}
+
+}  // namespace hgnn
+
+using namespace hgnn;
+
+extern "C" int hgnn_mlp_supported(const hgnn_mlp_desc* d) {
+    if (d == nullptr) return 0;
+    if (d->n_seg < 1 || d->n_seg > 3 || (d->n_layers != 2 && d->n_layers != 3)) return 0;
+    int k = 0;
+    for (int s = 0; s < d->n_seg; ++s) {
+        if (d->seg_width[s] <= 0 || d->seg_width[s] % 16 != 0) return 0;
+        k += d->seg_width[s];
+    }
+    if (k != d->width[0]) return 0;
+    for (int l = 0; l < d->n_layers; ++l)
+        if (d->ln_w[l] == nullptr || d->ln_b[l] == nullptr || d->W[l] == nullptr || d->b[l] == nullptr) return 0;
+    const int h = d->width[1];
+    const int o = d->width[d->n_layers];
+    if (d->n_layers == 3 && d->width[2] != h) return 0;
+    if (h != 2 * o) return 0;
+    return (o == 32 || o == 64 || o == 128 || o == 256) ? 1 : 0;
+}
+
+extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HGNN_REQUIRE(d != nullptr && out != nullptr, "hgnn_mlp_forward_f32: NULL argument");
+    if (!hgnn_mlp_supported(d)) {
+        set_error("hgnn_mlp_forward_f32: unsupported shape (segments must be multiples of 16 wide, "
+                  "LayerNorm on every layer, widths K -> 2L (-> 2L) -> L with L in {32,64,128,256})");
+        return HGNN_ERR_UNSUPPORTED;
+    }
+    if (d->M == 0) return HGNN_OK;
+    HGNN_REQUIRE(d->M > 0 && d->M < ((int64_t)1 << 31) * 64, "hgnn_mlp_forward_f32: bad M");
+    MlpArgs a;
+    for (int s = 0; s < 3; ++s) {
+        a.seg_table[s] = s < d->n_seg ? d->seg_table[s] : nullptr;
+        a.seg_index[s] = s < d->n_seg ? d->seg_index[s] : nullptr;
+        a.seg_width[s] = s < d->n_seg ? d->seg_width[s] : 0;
+        if (s < d->n_seg) {
+            HGNN_REQUIRE(a.seg_table[s] != nullptr && (uintptr_t)a.seg_table[s] % 16 == 0,
+                         "hgnn_mlp_forward_f32: segment table %d is NULL or not 16-byte aligned", s);
+        }
+    }
+    a.n_seg = d->n_seg;
+    a.K1 = d->width[0];
+    for (int l = 0; l < 3; ++l) {
+        const bool on = l < d->n_layers;
+        a.W[l] = on ? d->W[l] : nullptr;
+        a.b[l] = on ? d->b[l] : nullptr;
+        a.lnw[l] = on ? d->ln_w[l] : nullptr;
+        a.lnb[l] = on ? d->ln_b[l] : nullptr;
+        a.act[l] = on ? d->act[l] : 0;
+        if (on) {
+            HGNN_REQUIRE((uintptr_t)a.W[l] % 16 == 0 && (uintptr_t)a.b[l] % 16 == 0 &&
+                             (uintptr_t)a.lnw[l] % 16 == 0 && (uintptr_t)a.lnb[l] % 16 == 0,
+                         "hgnn_mlp_forward_f32: layer %d parameters must be 16-byte aligned", l);
+        }
+    }
+    a.eps = d->ln_eps;
+    a.skip = d->skip;
+    a.out = out;
+    a.M = d->M;
+    HGNN_REQUIRE((uintptr_t)out % 16 == 0 && (uintptr_t)a.skip % 16 == 0,
+                 "hgnn_mlp_forward_f32: out/skip must be 16-byte aligned");
+    const int o = d->width[d->n_layers];
+    if (d->n_layers == 2) {
+        switch (o) {
+            case 32: return launch_mlp<4, 2, 0, 2>(a, stream);
+            case 64: return launch_mlp<8, 4, 0, 2>(a, stream);
+            case 128: return launch_mlp<16, 8, 0, 2>(a, stream);
+            case 256: return launch_mlp<32, 16, 0, 2>(a, stream);
+        }
+    } else {
+        switch (o) {
+            case 32: return launch_mlp<4, 4, 2, 2>(a, stream);
+            case 64: return launch_mlp<8, 8, 4, 2>(a, stream);
+            case 128: return launch_mlp<16, 16, 8, 2>(a, stream);
+            case 256: return launch_mlp<32, 32, 16, 1>(a, stream);
+        }
+    }
+    set_error("hgnn_mlp_forward_f32: no instantiation");
+    return HGNN_ERR_UNSUPPORTED;
+}

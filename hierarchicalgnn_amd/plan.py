@@ -139,7 +139,45 @@ def get_plan(dst_index: torch.Tensor, dim_size: int, gather_index: Optional[torc
 
 def clear_plan_cache():
     _CACHE.clear()
+    _IDX_CACHE.clear()
 
 
 def plan_cache_stats():
     return dict(_STATS, size=len(_CACHE))
+
+
+# --------------------------------------------------------------------------- int32 gather indices
+_IDX_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
+
+
+def get_index32(index: torch.Tensor, limit: int) -> torch.Tensor:
+    """cached, range-checked int32 copy of an int64 gather index (``graph[0]`` ...) for the
+    fused MLP kernel; same identity/version keying as ``get_plan``."""
+    if not index.is_cuda or index.dtype != torch.int64 or index.dim() != 1:
+        raise RuntimeError("get_index32: index must be a 1-D int64 HIP tensor")
+    key = (_key(index), int(limit))
+    hit = _IDX_CACHE.get(key)
+    if hit is not None:
+        _IDX_CACHE.move_to_end(key)
+        return hit[0]
+    # reuse a destination plan's dst32 if one exists for this index (same contents)
+    for (k_dst, k_n, k_g, _), (plan, _, _) in _CACHE.items():
+        if k_dst == key[0] and k_g is None and k_n == int(limit):
+            out = plan.dst32[:index.numel()] if index.numel() else plan.dst32[:0]
+            _IDX_CACHE[key] = (out, index)
+            return out
+    lib = _lib.load()
+    M = int(index.numel())
+    out = torch.empty(max(M, 1), dtype=torch.int32, device=index.device)
+    err = torch.zeros(1, dtype=torch.int32, device=index.device)
+    with torch.cuda.device(index.device):
+        idx_c = index.contiguous()
+        _lib.check(lib.hgnn_index_to_i32(_lib.ptr(idx_c), M, int(limit), _lib.ptr(out), _lib.ptr(err),
+                                         _lib.current_stream(index.device)), "hgnn_index_to_i32")
+    if int(err.item()) != 0:
+        raise RuntimeError(f"gather index out of range for a table of {limit} rows")
+    out = out[:M]
+    _IDX_CACHE[key] = (out, index)
+    while len(_IDX_CACHE) > _CACHE_SIZE:
+        _IDX_CACHE.popitem(last=False)
+    return out

@@ -26,6 +26,10 @@
  *   hgnn_edge_dot_f32
  *       backward of the weighted forms w.r.t. the weights (autograd of
  *       Modules/gnn_utils.py:124,142,143).
+ *   hgnn_mlp_forward_f32
+ *       the make_mlp Sequential (Modules/utils.py:169-196) of the edge / node networks
+ *       fused with the concat + gathers feeding it and the skip connection
+ *       (Modules/gnn_utils.py:52-53, :61-62): see the section at the end.
  */
 #ifndef HGNN_HIP_H
 #define HGNN_HIP_H
@@ -43,7 +47,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 1
+#define HGNN_ABI_VERSION 2
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -85,7 +89,12 @@ typedef struct hgnn_plan {
 int hgnn_abi_version(void);
 const char* hgnn_last_error(void);
 
-/* Tuning switches for A/B measurements ("nt_loads", "nt_stores"); process-wide. */
+/* sizeof(hgnn_plan) / sizeof(hgnn_mlp_desc) as compiled: lets a foreign-language binding
+ * verify its struct mirror. */
+int hgnn_sizeof_plan(void);
+int hgnn_sizeof_mlp_desc(void);
+
+/* Tuning switches for A/B measurements ("nt_loads", "nt_stores", "seg_unroll", "seg_wpb", "seg_xcd"); process-wide. */
 int hgnn_set_option(const char* name, int value);
 
 /* Fills n_rows/n_dst/n_src/chunk/max_* of `plan` (pointers untouched).
@@ -126,6 +135,47 @@ int hgnn_edge_dot_f32(const float* A, const int32_t* ai, int64_t a_rows,
 /* int64 -> int32 index conversion with range check (out-of-range -> -1, err flag set) */
 int hgnn_index_to_i32(const int64_t* idx, int64_t M, int64_t limit, int32_t* out,
                       int32_t* err_flag, hgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused gather -> concat -> Linear -> LayerNorm -> act -> ... -> (+skip) MLP
+ * (fp32 MFMA).  One descriptor describes up to 3 concatenated input segments,
+ * each an optional row gather of a table, and up to 3 Linear layers with
+ * LayerNorm + activation after each (make_mlp with layer_norm=True,
+ * reference Modules/utils.py:169-196), as instantiated for the edge / node /
+ * supernode / superedge networks at Modules/gnn_utils.py:22-41 and :77-115,
+ * fused with the concat + gathers feeding them (:52,:61,:126,:134,:144,:152)
+ * and the skip connection (:53,:62,:126,:134,:144,:152).  "K6+K7".
+ * ------------------------------------------------------------------------ */
+#define HGNN_ACT_NONE 0
+#define HGNN_ACT_GELU 1 /* erf form, nn.GELU() default */
+#define HGNN_ACT_TANH 2
+#define HGNN_ACT_RELU 3
+
+typedef struct hgnn_mlp_desc {
+    int32_t n_seg;               /* 1..3 input segments, concatenated in order    */
+    const float* seg_table[3];   /* [rows_i, seg_width[i]]                        */
+    const int32_t* seg_index[3]; /* int32[M] row gather, or NULL (row e)          */
+    int32_t seg_width[3];
+    int32_t n_layers;            /* 1..3                                          */
+    const float* W[3];           /* Linear weight [out_i, in_i] row-major (torch) */
+    const float* b[3];           /* [out_i]                                       */
+    const float* ln_w[3];        /* LayerNorm affine, NULL = no LayerNorm         */
+    const float* ln_b[3];
+    int32_t width[4];            /* in, h1, (h2), out                             */
+    int32_t act[3];              /* HGNN_ACT_* after each layer                   */
+    float ln_eps;
+    const float* skip;           /* [M, out] added to the result, or NULL         */
+    int64_t M;                   /* rows                                          */
+} hgnn_mlp_desc;
+
+/* 1 if hgnn_mlp_forward_f32 has an instantiation for this descriptor (host-only check):
+ * every segment a multiple of 16 floats wide, LayerNorm on every layer, widths
+ * K -> 2L (-> 2L) -> L with L in {32, 64, 128, 256}. */
+int hgnn_mlp_supported(const hgnn_mlp_desc* d);
+
+/* out[M, L] = MLP(cat_i seg_i[idx_i]) (+ skip).  No workspace; hidden activations stay in
+ * registers.  Negative gather indices read row 0 (callers validate indices at plan build). */
+int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -55,9 +55,28 @@ def test_plan_dims_host_logic():
     assert rc != 0
 
 
-def test_plan_struct_layout_matches_header():
-    # 3*8 + 2*4 + 3*8 + 10 pointers
-    assert ctypes.sizeof(_lib.HgnnPlan) == 24 + 8 + 24 + 80
+def test_struct_mirrors_match_the_compiled_layout():
+    lib = _lib.load()
+    assert ctypes.sizeof(_lib.HgnnPlan) == lib.hgnn_sizeof_plan() == 24 + 8 + 24 + 80
+    assert ctypes.sizeof(_lib.HgnnMlpDesc) == lib.hgnn_sizeof_mlp_desc()
+
+
+def test_mlp_supported_is_a_host_side_shape_check():
+    lib = _lib.load()
+    d = _lib.HgnnMlpDesc()
+    assert lib.hgnn_mlp_supported(ctypes.byref(d)) == 0
+    d.n_seg, d.n_layers = 3, 2
+    for i in range(3):
+        d.seg_width[i] = 256
+    d.width[0], d.width[1], d.width[2] = 768, 512, 256
+    for l in range(2):
+        d.W[l] = d.b[l] = d.ln_w[l] = d.ln_b[l] = 64  # non-NULL
+    assert lib.hgnn_mlp_supported(ctypes.byref(d)) == 1
+    d.width[1] = 500                                    # H != 2L
+    assert lib.hgnn_mlp_supported(ctypes.byref(d)) == 0
+    d.width[1] = 512
+    d.seg_width[0] = 250                                # segment not a multiple of 16
+    assert lib.hgnn_mlp_supported(ctypes.byref(d)) == 0
 
 
 def test_unknown_option_is_an_error():

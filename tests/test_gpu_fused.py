@@ -1,0 +1,133 @@
+"""GPU parity of the fused gather->concat->MLP(+skip) fp32-MFMA kernel (K6+K7) through
+``hgnn_mlp_forward_f32``: against the CPU oracle, the golden cell fixtures, and the
+unfused GPU path at BASELINE widths."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _mk(in_w, L, layers, out_act, seed):
+    from hierarchicalgnn_amd import make_mlp
+    torch.manual_seed(seed)
+    net = make_mlp(in_w, 2 * L, L, layers, layer_norm=True, output_activation=out_act, hidden_activation="GELU")
+    for p in net.parameters():  # non-trivial LayerNorm affine / biases
+        if p.dim() == 1:
+            p.data.add_(0.2 * torch.randn_like(p))
+    return net
+
+
+@pytest.mark.parametrize("L,layers,nseg,M", [
+    (32, 2, 3, 1000), (64, 2, 3, 777), (128, 2, 3, 515), (256, 2, 3, 300),
+    (32, 3, 2, 640), (64, 3, 3, 129), (128, 3, 2, 200), (256, 3, 3, 150), (256, 3, 2, 64), (128, 2, 1, 1)])
+def test_fused_mlp_vs_oracle(L, layers, nseg, M):
+    from hierarchicalgnn_amd import fused
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(L * 10 + layers)
+    out_act = "Tanh" if layers == 2 else "GELU"
+    net = _mk(nseg * L, L, layers, out_act, seed=L + layers)
+    n_tab = 97
+    table = torch.randn(n_tab, L, generator=g)
+    idx0 = torch.randint(0, n_tab, (M,), generator=g)
+    idx1 = torch.randint(0, n_tab, (M,), generator=g)
+    direct = torch.randn(M, L, generator=g)
+    segs_cpu = [(table, idx0), (table, idx1), (direct, None)][3 - nseg:]
+    x = torch.cat([t if i is None else t[i] for t, i in segs_cpu], dim=1)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = O.mlp_apply(sd, "", x, layers, "GELU", out_act, True) + direct
+    net = net.cuda()
+    segs = [(t.cuda(), None if i is None else i.cuda()) for t, i in segs_cpu]
+    with torch.no_grad():
+        assert fused.supported(net, segs, segs[-1][0])
+        n0 = fused.stats["fused_calls"]
+        out = fused.fused_concat_mlp(net, segs, segs[-1][0])
+        assert fused.stats["fused_calls"] == n0 + 1
+    assert out.shape == ref.shape
+    assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
+
+
+def test_fused_not_used_when_grad_is_recorded():
+    from hierarchicalgnn_amd import fused
+    net = _mk(3 * 32, 32, 2, "Tanh", 1).cuda()
+    e = torch.randn(10, 32).cuda().requires_grad_(True)
+    t = torch.randn(5, 32).cuda()
+    i = torch.randint(0, 5, (10,)).cuda()
+    assert not fused.supported(net, [(t, i), (t, i), (e, None)], e)
+    with torch.no_grad():
+        assert fused.supported(net, [(t, i), (t, i), (e, None)], e)
+
+
+def test_unsupported_shapes_fall_to_library_path():
+    from hierarchicalgnn_amd import fused, make_mlp
+    with torch.no_grad():
+        enc = make_mlp(3, 64, 32, 3, layer_norm=True).cuda()          # node encoder: K=3
+        assert not fused.supported(enc, [(torch.randn(9, 3).cuda(), None)], None)
+        head = make_mlp(64, 64, 1, 3, layer_norm=True, output_activation=None).cuda()
+        assert not fused.supported(head, [(torch.randn(9, 64).cuda(), None)], None)
+
+
+@pytest.mark.parametrize("latent", [32, 128])
+def test_interaction_cell_inference_uses_fused_and_matches_reference(latent):
+    import hierarchicalgnn_amd as H
+    from hierarchicalgnn_amd import fused
+    z = load_golden(f"ignn_cell_L{latent}.npz")
+    hp = dict(latent=latent, hidden=2 * latent, nb_edge_layer=2, nb_node_layer=3, layernorm=True,
+              hidden_activation="GELU")
+    cell = H.InteractionGNNCell(hp)
+    cell.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")})
+    cell = cell.cuda()
+    n0 = fused.stats["fused_calls"]
+    with torch.no_grad():
+        on, oe = cell(torch.from_numpy(z["nodes"]).cuda(), torch.from_numpy(z["edges"]).cuda(),
+                      torch.from_numpy(z["graph"]).cuda())
+    assert fused.stats["fused_calls"] == n0 + 2          # node network + edge network
+    assert rel_err(on.cpu().numpy(), z["out_nodes"]) <= TOL
+    assert rel_err(oe.cpu().numpy(), z["out_edges"]) <= TOL
+
+
+@pytest.mark.parametrize("latent", [32, 64])
+def test_hierarchical_cell_inference_uses_fused_and_matches_reference(latent):
+    import hierarchicalgnn_amd as H
+    from hierarchicalgnn_amd import fused
+    z = load_golden(f"hgnn_cell_L{latent}.npz")
+    hp = dict(latent=latent, hidden=2 * latent, nb_edge_layer=2, nb_node_layer=3, layernorm=True,
+              hidden_activation="GELU")
+    cell = H.HierarchicalGNNCell(hp)
+    cell.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")})
+    cell = cell.cuda()
+    names = ("nodes", "edges", "supernodes", "superedges")
+    n0 = fused.stats["fused_calls"]
+    with torch.no_grad():
+        outs = cell(*[torch.from_numpy(z[k]).cuda() for k in names],
+                    torch.from_numpy(z["graph"]).cuda(), torch.from_numpy(z["bipartite_graph"]).cuda(),
+                    torch.from_numpy(z["bipartite_edge_weights"]).cuda(), torch.from_numpy(z["super_graph"]).cuda(),
+                    torch.from_numpy(z["super_edge_weights"]).cuda())
+    assert fused.stats["fused_calls"] == n0 + 4
+    for nm, o in zip(names, outs):
+        assert rel_err(o.cpu().numpy(), z["out_" + nm]) <= TOL, nm
+
+
+def test_fused_vs_unfused_at_baseline_width():
+    """L=256 (BASELINE headline width), 200k edges: fused MFMA kernel vs gather + library GEMMs"""
+    import hierarchicalgnn_amd as H
+    from hierarchicalgnn_amd import fused, mlp, synth
+    torch.manual_seed(0)
+    L = 256
+    x, ei = synth.trackml_event(12_000, 100_000, seed=2)
+    graph = synth.directed(ei).cuda()
+    nodes = torch.randn(12_000, L, device="cuda")
+    edges = torch.randn(graph.shape[1], L, device="cuda")
+    net = _mk(3 * L, L, 2, "Tanh", 3).cuda()
+    segs = [(nodes, graph[0]), (nodes, graph[1]), (edges, None)]
+    with torch.no_grad():
+        a = mlp.concat_mlp(net, segs, skip=edges)
+        fused.set_enabled(False)
+        try:
+            b = mlp.concat_mlp(net, segs, skip=edges)
+        finally:
+            fused.set_enabled(True)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL
