@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Secondary measurements at the BASELINE shape (N=120k, M=2M): every kernel of the
+message-passing cell, fused vs library path.  Usage: python tools/bench_cell.py [L]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import hierarchicalgnn_amd as H
+from hierarchicalgnn_amd import fused, mlp, synth
+
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+torch.manual_seed(0)
+x, ei = synth.trackml_event()
+graph = synth.directed(ei).cuda()
+N, M = 120_000, graph.shape[1]
+nodes = torch.randn(N, L, device="cuda")
+edges = torch.randn(M, L, device="cuda")
+hp = dict(latent=L, hidden=2 * L, nb_edge_layer=2, nb_node_layer=3, layernorm=True, hidden_activation="GELU")
+cell = H.InteractionGNNCell(hp).cuda()
+bg, bw = synth.bipartite_assignment(N, 10_000, 5)
+bg, bw = bg.cuda(), bw.cuda()
+S = 10_000
+sn = torch.randn(S, L, device="cuda")
+
+
+def timeit(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+res = {"L": L, "N": N, "M": M}
+with torch.no_grad():
+    res["k1_scatter_add_ms"] = timeit(lambda: H.scatter_add(edges, graph[1], dim_size=N), 20)
+    g = torch.randn(N, L, device="cuda")
+    plan = H.get_plan(graph[1], N)
+    from hierarchicalgnn_amd.ops import _gather_rows
+    res["k1_backward_gather_ms"] = timeit(lambda: _gather_rows(g, plan.dst32, M), 20)
+    res["k6_gather_rows_ms"] = timeit(lambda: H.gather_rows(nodes, graph[0]), 20)
+    res["k3_node_to_supernode_ms"] = timeit(lambda: H.gather_scale_scatter(nodes, bg[0], bg[1], S, bw), 20)
+    res["k2_supernode_to_node_ms"] = timeit(lambda: H.gather_scale_scatter(sn, bg[1], bg[0], N, bw), 20)
+    rs = H.l1_row_scale(nodes)
+    res["k5_pool_ms"] = timeit(lambda: H.gather_scale_scatter(nodes, bg[0], bg[1], S, bw, row_scale=rs), 20)
+    flop_edge = 2 * (3 * L * 2 * L + 2 * L * L) * M
+    flop_node = 2 * (2 * L * 2 * L + 2 * L * 2 * L + 2 * L * L) * N
+    for name, on in (("fused", True), ("library", False)):
+        fused.set_enabled(on)
+        t = timeit(lambda: cell._edge_update(nodes, edges, graph), 5, 1)
+        res[f"edge_update_{name}_ms"] = t
+        res[f"edge_update_{name}_tflops"] = flop_edge / t / 1e9
+        t = timeit(lambda: cell._node_update(nodes, edges, graph), 5, 1)
+        res[f"node_update_{name}_ms"] = t
+        res[f"node_mlp_{name}_tflops_incl_scatter"] = flop_node / t / 1e9
+        res[f"cell_forward_{name}_ms"] = timeit(lambda: cell(nodes, edges, graph), 5, 1)
+    fused.set_enabled(True)
+print(json.dumps(res, indent=1))
