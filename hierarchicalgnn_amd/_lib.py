@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HgnnPlan(Structure):
@@ -26,7 +26,7 @@ class HgnnPlan(Structure):
         ("chunk", c_int32), ("has_gather", c_int32),
         ("max_work", c_int64), ("max_split", c_int64), ("max_partial", c_int64),
         ("perm", c_void_p), ("src_row", c_void_p), ("dst32", c_void_p), ("rowptr", c_void_p),
-        ("wi_begin", c_void_p), ("wi_end", c_void_p), ("wi_target", c_void_p),
+        ("wi_begin", c_void_p), ("wi_end", c_void_p), ("wi_target", c_void_p), ("wi_dst", c_void_p),
         ("split_dst", c_void_p), ("split_pbegin", c_void_p), ("counts", c_void_p),
     ]
 
@@ -58,6 +58,7 @@ _SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p]),
     "hgnn_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
+    "hgnn_spread_rows_f32": (c_int, [POINTER(HgnnPlan), c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "hgnn_edge_dot_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                   c_int64, c_void_p, c_void_p]),
     "hgnn_index_to_i32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

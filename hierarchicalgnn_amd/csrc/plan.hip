@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t* __restrict__ r
             plan.wi_begin[item] = b;
             plan.wi_end[item] = e;
             plan.wi_target[item] = split ? ~(t.c + k) : (int32_t)d;
+            plan.wi_dst[item] = (int32_t)d;
         }
     }
     if (split && t.b < plan.max_split) {
@@ -212,7 +213,7 @@ extern "C" int hgnn_plan_build(const int64_t* dst_index, const int64_t* gather_i
     HGNN_REQUIRE(M == 0 || dst_index != nullptr, "hgnn_plan_build: dst_index is NULL");
     HGNN_REQUIRE(plan->chunk > 0 && plan->max_work >= N + M / plan->chunk + 1,
                  "hgnn_plan_build: plan dims not initialised (call hgnn_plan_dims)");
-    HGNN_REQUIRE(plan->counts && plan->rowptr && (N == 0 || (plan->wi_begin && plan->wi_end && plan->wi_target)) &&
+    HGNN_REQUIRE(plan->counts && plan->rowptr && (N == 0 || (plan->wi_begin && plan->wi_end && plan->wi_target && plan->wi_dst)) &&
                      plan->split_dst && plan->split_pbegin &&
                      (M == 0 || (plan->perm && plan->src_row && plan->dst32)),
                  "hgnn_plan_build: a plan array pointer is NULL");

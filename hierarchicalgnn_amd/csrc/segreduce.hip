@@ -226,6 +226,81 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
     }
 }
 
+// Transpose of k_seg_reduce: walk the plan in destination order, read each table row once and
+// write it (scaled) to every row of its list.  out[perm[p],:] = w[perm[p]] * table[dst,:].
+template <int RL, int VPL, bool HAS_W, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_spread_rows(
+    const float* __restrict__ table, int F, int nvec, const int32_t* __restrict__ perm,
+    const float* __restrict__ weight, const int32_t* __restrict__ wi_begin,
+    const int32_t* __restrict__ wi_end, const int32_t* __restrict__ wi_dst,
+    const int32_t* __restrict__ n_items_ptr, int64_t max_items, float* __restrict__ out, bool nt_store) {
+    constexpr int G = 64 / RL;
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int n_items = *n_items_ptr;
+    if (item >= n_items || item >= max_items) return;
+    const int begin = __builtin_amdgcn_readfirstlane(wi_begin[item]);
+    const int end = __builtin_amdgcn_readfirstlane(wi_end[item]);
+    if (begin >= end) return;
+    const int dst = __builtin_amdgcn_readfirstlane(wi_dst[item]);
+    const int g = lane / RL;
+    const int c = lane % RL;
+    f32x4 row[VPL];
+    const float* rp = table + (size_t)dst * (size_t)F;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int cv = c + v * 64;
+        row[v] = cv < nvec ? *(const f32x4*)(rp + cv * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int base = begin; base < end; base += 64) {
+        const int n = (end - base) < 64 ? (end - base) : 64;
+        int my_e = 0;
+        float my_w = 1.f;
+        if (lane < n) {
+            my_e = perm[base + lane];
+            if (HAS_W) my_w = weight[my_e];
+        }
+        for (int j = 0; j < n; j += G) {
+            const int k = j + g;
+            const int e = __shfl(my_e, k & 63);
+            const float w = HAS_W ? __shfl(my_w, k & 63) : 1.f;
+            if (k < n) {
+                float* op = out + (size_t)e * (size_t)F;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    const int cv = c + v * 64;
+                    if (cv < nvec) {
+                        const f32x4 x = HAS_W ? row[v] * w : row[v];
+                        if (nt_store)
+                            __builtin_nontemporal_store(x, (f32x4*)(op + cv * 4));
+                        else
+                            *(f32x4*)(op + cv * 4) = x;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool HAS_W>
+__global__ __launch_bounds__(256) void k_spread_rows_scalar(
+    const float* __restrict__ table, int F, const int32_t* __restrict__ perm,
+    const float* __restrict__ weight, const int32_t* __restrict__ wi_begin,
+    const int32_t* __restrict__ wi_end, const int32_t* __restrict__ wi_dst,
+    const int32_t* __restrict__ n_items_ptr, int64_t max_items, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int n_items = *n_items_ptr;
+    if (item >= n_items || item >= max_items) return;
+    const int begin = wi_begin[item], end = wi_end[item], dst = wi_dst[item];
+    for (int p = begin; p < end; ++p) {
+        const int e = perm[p];
+        const float w = HAS_W ? weight[e] : 1.f;
+        for (int col = lane; col < F; col += 64)
+            out[(size_t)e * F + col] = w * table[(size_t)dst * F + col];
+    }
+}
+
 template <bool HAS_W, bool HAS_RS>
 __global__ __launch_bounds__(256) void k_gather_rows_scalar(const float* __restrict__ table, int F,
                                                             const int32_t* __restrict__ idx, int64_t M,
@@ -513,6 +588,56 @@ extern "C" int hgnn_gather_rows_f32(const float* table, int64_t table_rows, int3
     else if (weight) rc = dispatch_gather<true, false>(table, F, idx, M, weight, row_scale, out, stream);
     else if (row_scale) rc = dispatch_gather<false, true>(table, F, idx, M, weight, row_scale, out, stream);
     else rc = dispatch_gather<false, false>(table, F, idx, M, weight, row_scale, out, stream);
+    if (rc != HGNN_OK) return rc;
+    HGNN_CHECK_HIP(hipGetLastError());
+    return HGNN_OK;
+}
+
+template <bool W>
+static int dispatch_spread(const hgnn_plan* plan, const float* table, int F, const float* weight, float* out,
+                           hipStream_t s) {
+    const int64_t max_items = plan->max_work;
+    const int32_t* n_items = plan->counts + HGNN_CNT_WORK;
+    if (F % 4 != 0 || F > 1024) {
+        const unsigned grid = (unsigned)ceil_div(max_items, kWavesPerBlock);
+        if (grid)
+            k_spread_rows_scalar<W><<<grid, kBlock, 0, s>>>(table, F, plan->perm, weight, plan->wi_begin,
+                                                           plan->wi_end, plan->wi_dst, n_items, max_items, out);
+        return HGNN_OK;
+    }
+    const int nvec = F / 4;
+    const bool nt = g_opt_nt_stores != 0;
+#define HGNN_S(RL, VPL, WPB)                                                                          \
+    do {                                                                                              \
+        const unsigned grid = (unsigned)ceil_div(max_items, WPB);                                     \
+        if (grid)                                                                                     \
+            k_spread_rows<RL, VPL, W, WPB><<<grid, WPB * 64, 0, s>>>(table, F, nvec, plan->perm, weight,   \
+                                                                     plan->wi_begin, plan->wi_end,    \
+                                                                     plan->wi_dst, n_items, max_items, out, nt); \
+    } while (0)
+    if (nvec <= 4) HGNN_S(4, 1, 4);
+    else if (nvec <= 8) HGNN_S(8, 1, 4);
+    else if (nvec <= 16) HGNN_S(16, 1, 4);
+    else if (nvec <= 32) HGNN_S(32, 1, 4);
+    else if (nvec <= 64) HGNN_S(64, 1, 8);
+    else if (nvec <= 128) HGNN_S(64, 2, 8);
+    else HGNN_S(64, 4, 8);
+#undef HGNN_S
+    return HGNN_OK;
+}
+
+extern "C" int hgnn_spread_rows_f32(const hgnn_plan* plan, const float* table, int32_t F, const float* weight,
+                                    float* out, hgnn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HGNN_REQUIRE(plan != nullptr, "hgnn_spread_rows_f32: plan is NULL");
+    HGNN_REQUIRE(F > 0, "hgnn_spread_rows_f32: F must be positive");
+    if (plan->n_rows == 0 || plan->n_dst == 0) return HGNN_OK;
+    HGNN_REQUIRE(!plan->has_gather, "hgnn_spread_rows_f32: plan must be a plain destination plan");
+    HGNN_REQUIRE(table != nullptr && out != nullptr, "hgnn_spread_rows_f32: NULL pointer");
+    HGNN_REQUIRE(((uintptr_t)table % 16 == 0 && (uintptr_t)out % 16 == 0) || F % 4 != 0,
+                 "hgnn_spread_rows_f32: table/out must be 16-byte aligned");
+    int rc = weight ? dispatch_spread<true>(plan, table, F, weight, out, stream)
+                    : dispatch_spread<false>(plan, table, F, weight, out, stream);
     if (rc != HGNN_OK) return rc;
     HGNN_CHECK_HIP(hipGetLastError());
     return HGNN_OK;

@@ -60,6 +60,21 @@ def _gather_rows(table: torch.Tensor, idx32: torch.Tensor, M: int, weight: Optio
     return out
 
 
+def _spread_rows(plan: GraphPlan, table: torch.Tensor, weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[e] = w[e] * table[index[e]] walked in destination order (each table row read once)"""
+    F = int(table.shape[1])
+    alloc = torch.empty if plan.validated else torch.zeros
+    out = alloc((plan.M, F), dtype=torch.float32, device=table.device)
+    if plan.M == 0 or F == 0:
+        return out
+    lib = _lib.load()
+    with torch.cuda.device(table.device):
+        _lib.check(lib.hgnn_spread_rows_f32(ctypes.byref(plan.c), _lib.ptr(table), F, _lib.ptr(weight),
+                                            _lib.ptr(out), _lib.current_stream(table.device)),
+                   "hgnn_spread_rows_f32")
+    return out
+
+
 def _edge_dot(A: torch.Tensor, ai: Optional[torch.Tensor], B: torch.Tensor, bi: Optional[torch.Tensor],
               M: int) -> torch.Tensor:
     F = int(A.shape[1])
@@ -97,11 +112,11 @@ class _ScatterAdd(torch.autograd.Function):
         if ctx.has_w:
             src_c, w_c = ctx.saved_tensors
             if ctx.needs_input_grad[0]:
-                grad_src = _gather_rows(g, plan.dst32, plan.M, weight=w_c)
+                grad_src = _spread_rows(plan, g, weight=w_c)
             if ctx.needs_input_grad[1]:
                 grad_w = _edge_dot(src_c, None, g, plan.dst32, plan.M).view(ctx.w_shape)
         elif ctx.needs_input_grad[0]:
-            grad_src = _gather_rows(g, plan.dst32, plan.M)
+            grad_src = _spread_rows(plan, g)
         return grad_src, grad_w, None
 
 
@@ -216,7 +231,7 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, plan: GraphPlan):
         ctx.plan = plan
-        return _gather_rows(table.contiguous(), plan.dst32, plan.M)
+        return _spread_rows(plan, table.contiguous())
 
     @staticmethod
     def backward(ctx, grad_out):

@@ -77,10 +77,11 @@ class GraphPlan:
             self.wi_begin = _i32(c.max_work, dev)
             self.wi_end = _i32(c.max_work, dev)
             self.wi_target = _i32(c.max_work, dev)
+            self.wi_dst = _i32(c.max_work, dev)
             self.split_dst = _i32(c.max_split, dev)
             self.split_pbegin = _i32(c.max_split + 1, dev)
             self.counts = torch.zeros(8, dtype=torch.int32, device=dev)
-            for name in ("perm", "src_row", "dst32", "rowptr", "wi_begin", "wi_end", "wi_target",
+            for name in ("perm", "src_row", "dst32", "rowptr", "wi_begin", "wi_end", "wi_target", "wi_dst",
                          "split_dst", "split_pbegin", "counts"):
                 setattr(c, name, getattr(self, name).data_ptr())
             nbytes = ctypes.c_size_t(0)
@@ -91,6 +92,7 @@ class GraphPlan:
             # `ws`, `dst_c`, `gat_c` are only used by kernels already enqueued on this
             # stream; the caching allocator orders their reuse after them.
         self.c = c
+        self.validated = bool(validate)
         self._partial = {}
         _STATS["built"] += 1
         if validate:

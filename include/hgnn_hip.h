@@ -20,6 +20,9 @@
  *       scatter_add(w * X[g], d, dim_size) at Modules/gnn_utils.py:124 ("K2"),
  *       :142 ("K3") and, with a per-row L1 scale,
  *       BipartiteClassification/Models/HGNN_GMM.py:269 ("K5").
+ *   hgnn_spread_rows_f32
+ *       backward of scatter_add (grad_src[e] = grad_out[index[e]]) and the gathers
+ *       nodes[graph[0]], nodes[graph[1]] (Modules/gnn_utils.py:61) in destination order.
  *   hgnn_gather_rows_f32
  *       the row gathers nodes[graph[0]], nodes[graph[1]] at
  *       Modules/gnn_utils.py:61,134,152 ("K6"); also the backward of scatter_add.
@@ -47,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 2
+#define HGNN_ABI_VERSION 3
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -81,6 +84,7 @@ typedef struct hgnn_plan {
     int32_t* wi_begin;    /* [max_work]                                           */
     int32_t* wi_end;      /* [max_work]                                           */
     int32_t* wi_target;   /* [max_work] >=0: output row; <0: ~partial row         */
+    int32_t* wi_dst;      /* [max_work] destination of the item (also for chunks) */
     int32_t* split_dst;   /* [max_split]                                          */
     int32_t* split_pbegin;/* [max_split+1] partial-row range of each split dst    */
     int32_t* counts;      /* [8]                                                  */
@@ -125,6 +129,16 @@ int hgnn_gather_rows_f32(const float* table, int64_t table_rows, int32_t F,
                          const int32_t* idx, int64_t M,
                          const float* weight, const float* row_scale,
                          float* out, hgnn_stream_t stream);
+
+/* The transpose of hgnn_segment_reduce_f32 (= backward of scatter_add, and the row gather
+ * table[index] when the plan was built on `index`):
+ *     out[e,:] = weight[e] * table[dst(e),:]      for every row e of the plan
+ * walked in DESTINATION order: each table row is read once and written to the rows of its
+ * list, so HBM sees one pass of 16-B stores over out[M,F] instead of M random row reads.
+ * weight (float[M], by original position) may be NULL.  Rows whose index was out of range
+ * are not written. */
+int hgnn_spread_rows_f32(const hgnn_plan* plan, const float* table, int32_t F,
+                         const float* weight, float* out, hgnn_stream_t stream);
 
 /* out[e] = sum_f A[ai[e],f] * B[bi[e],f];  ai/bi int32[M] or NULL (identity);
  * negative index -> 0. */

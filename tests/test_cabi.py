@@ -57,7 +57,7 @@ def test_plan_dims_host_logic():
 
 def test_struct_mirrors_match_the_compiled_layout():
     lib = _lib.load()
-    assert ctypes.sizeof(_lib.HgnnPlan) == lib.hgnn_sizeof_plan() == 24 + 8 + 24 + 80
+    assert ctypes.sizeof(_lib.HgnnPlan) == lib.hgnn_sizeof_plan() == 24 + 8 + 24 + 88
     assert ctypes.sizeof(_lib.HgnnMlpDesc) == lib.hgnn_sizeof_mlp_desc()
 
 
