@@ -117,6 +117,39 @@ __device__ __forceinline__ void init_bias(f32x4 (&acc)[NT], const float* __restr
     for (int T = 0; T < NT; ++T) acc[T] = *(const f32x4*)(b + T * 16 + g * 4);
 }
 
+// One k-chunk (16 k-values) of one layer:  acc[T] += Wchunk[T] * b  for every 16-feature tile T.
+// Tiles are processed in pairs (two independent accumulators cover the 40-cycle dependent-issue
+// latency of v_mfma_f32_16x16x4_f32) and the NEXT pair's weight fragments are fetched from LDS
+// before the current pair's 8 MFMAs, pinned with sched_group_barrier so that hipcc does not
+// sink the reads back to their first use (it did: every 8 MFMAs waited on an lgkmcnt(0)).
+template <int NT>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[NT], const float* __restrict__ wb, const f32x4 b) {
+    static_assert(NT % 2 == 0, "tiles are processed in pairs");
+    f32x4 w0 = *(const f32x4*)(wb);
+    f32x4 w1 = *(const f32x4*)(wb + 256);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // pipeline prologue: the first pair's reads
+#pragma unroll
+    for (int T = 0; T < NT; T += 2) {
+        f32x4 n0 = w0, n1 = w1;
+        if (T + 2 < NT) {
+            n0 = *(const f32x4*)(wb + (T + 2) * 256);
+            n1 = *(const f32x4*)(wb + (T + 3) * 256);
+        }
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, b.x, acc[T], 0, 0, 0);
+        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, b.x, acc[T + 1], 0, 0, 0);
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, b.y, acc[T], 0, 0, 0);
+        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, b.y, acc[T + 1], 0, 0, 0);
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, b.z, acc[T], 0, 0, 0);
+        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, b.z, acc[T + 1], 0, 0, 0);
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, b.w, acc[T], 0, 0, 0);
+        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, b.w, acc[T + 1], 0, 0, 0);
+        w0 = n0;
+        w1 = n1;
+        if (T + 2 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads (next pair)
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                  // 8 MFMAs (this pair)
+    }
+}
+
 // one register-resident layer: out[NTO tiles] = W[NTO*16][NTI*16] * in  (in = previous accumulators)
 template <int NTI, int NTO>
 __device__ __forceinline__ void dense_from_regs(const f32x4 (&in)[NTI], f32x4 (&out)[NTO],
@@ -129,18 +162,7 @@ __device__ __forceinline__ void dense_from_regs(const f32x4 (&in)[NTI], f32x4 (&
     for (int c = 0; c < NTI; ++c) {
         __syncthreads();  // chunk c landed (vmcnt(0) precedes the barrier); buffer (c+1)&1 is free
         if (c + 1 < NTI) stage_w<NTO * 16>(W, KD, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
-        const float* wb = lds + (c & 1) * BUF + lane * 4;
-        f32x4 a = *(const f32x4*)wb;
-#pragma unroll
-        for (int T = 0; T < NTO; ++T) {
-            // fetch the next tile's weight fragment before this tile's MFMAs (hides the LDS latency)
-            const f32x4 an = *(const f32x4*)(wb + (T + 1 < NTO ? T + 1 : T) * 256);
-            out[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, in[c].x, out[T], 0, 0, 0);
-            out[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, in[c].y, out[T], 0, 0, 0);
-            out[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, in[c].z, out[T], 0, 0, 0);
-            out[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, in[c].w, out[T], 0, 0, 0);
-            a = an;
-        }
+        mma_chunk<NTO>(out, lds + (c & 1) * BUF + lane * 4, in[c]);
     }
 }
 
@@ -220,17 +242,7 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
             __syncthreads();
             if (c + 1 < nc) stage_w<NT1 * 16>(a.W[0], a.K1, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
             const f32x4 x2 = next_x(zero);
-            const float* wb = lds + (c & 1) * BUF + lane * 4;
-            f32x4 w = *(const f32x4*)wb;
-#pragma unroll
-            for (int T = 0; T < NT1; ++T) {
-                const f32x4 wn = *(const f32x4*)(wb + (T + 1 < NT1 ? T + 1 : T) * 256);
-                acc1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x0.x, acc1[T], 0, 0, 0);
-                acc1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x0.y, acc1[T], 0, 0, 0);
-                acc1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x0.z, acc1[T], 0, 0, 0);
-                acc1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x0.w, acc1[T], 0, 0, 0);
-                w = wn;
-            }
+            mma_chunk<NT1>(acc1, lds + (c & 1) * BUF + lane * 4, x0);
             x0 = x1;
             x1 = x2;
         }
