@@ -84,3 +84,84 @@ class EC_InteractionGNN(nn.Module):
         # IN.py:126 -- relies on the ORIGINAL edge order: edges[:E] pairs with edges[E:]
         scores = concat_mlp(self.edge_classifier, [(edges[:e], None), (edges[e:], None)]).squeeze(-1)
         return torch.sigmoid(scores)
+
+
+class HierarchicalGNNBlock(nn.Module):
+    """Message-passing part of BipartiteClassification/Models/HGNN_GMM.py:101-298.
+
+    The reference's block first decides the hierarchy (GMM cut, connected components,
+    kNN graphs: HGNN_GMM.py:244-260 -- host-side sklearn/scipy/cugraph/frnn calls, SURVEY
+    section 8f "next" rows) and then runs the arithmetic mirrored here on the result:
+    K5 pooling (:269), supernode / superedge encoders (:270-271) and the
+    HierarchicalGNNCell loop (:275-284).  ``forward`` therefore takes the hierarchy
+    (centroids ``means``, bipartite and super graphs with their weights) as inputs.
+    Sub-module names match the reference, so its ``hgnn_block.*`` weights load
+    (the graph-construction buffers it also holds are simply not used here).
+    """
+
+    def __init__(self, hparams):
+        super().__init__()
+        from .gnn_utils import HierarchicalGNNCell
+        act, ln = hparams["hidden_activation"], hparams["layernorm"]
+        self.supernode_encoder = make_mlp(hparams["latent"], hparams["hidden"],
+                                          hparams["latent"] - hparams["emb_dim"], hparams["nb_node_layer"],
+                                          output_activation=act, hidden_activation=act, layer_norm=ln)
+        self.superedge_encoder = make_mlp(2 * hparams["latent"], hparams["hidden"], hparams["latent"],
+                                          hparams["nb_edge_layer"], layer_norm=ln, output_activation=act,
+                                          hidden_activation=act)
+        n = hparams["n_hierarchical_graph_iters"]
+        if hparams["share_weight"]:
+            cell = HierarchicalGNNCell(hparams)
+            cells = [cell for _ in range(n)]
+        else:
+            cells = [HierarchicalGNNCell(hparams) for _ in range(n)]
+        self.hgnn_cells = nn.ModuleList(cells)
+        self.hparams = hparams
+        self._ckpt = bool(hparams.get("checkpointing", True))
+
+    def _encode_supernodes(self, pooled):
+        return concat_mlp(self.supernode_encoder, [(pooled, None)])
+
+    def _encode_superedges(self, supernodes, super_graph):
+        return concat_mlp(self.superedge_encoder, [(supernodes, super_graph[0]), (supernodes, super_graph[1])])
+
+    def forward(self, nodes, edges, graph, means, bipartite_graph, bipartite_edge_weights, super_graph,
+                super_edge_weights):
+        from .ops import gather_scale_scatter, l1_row_scale
+        # HGNN_GMM.py:269 -- L1-normalised rows, weighted, summed per supernode (K5, one fused kernel)
+        pooled = gather_scale_scatter(nodes, bipartite_graph[0], bipartite_graph[1], means.shape[0],
+                                      bipartite_edge_weights, row_scale=l1_row_scale(nodes))
+        supernodes = torch.cat([means, _maybe_checkpoint(self._ckpt, self._encode_supernodes, pooled)], dim=-1)
+        superedges = _maybe_checkpoint(self._ckpt, self._encode_superedges, supernodes, super_graph)
+        for cell in self.hgnn_cells:                                              # HGNN_GMM.py:275-284
+            nodes, edges, supernodes, superedges = cell(nodes, edges, supernodes, superedges, graph,
+                                                        bipartite_graph, bipartite_edge_weights,
+                                                        super_graph, super_edge_weights)
+        return nodes, supernodes, edges, superedges
+
+
+class BC_MessagePassing(nn.Module):
+    """The tensor arithmetic of BC_HierarchicalGNN_GMM (HGNN_GMM.py:300-346) around a given
+    hierarchy: IGNN block -> (hierarchy supplied by the caller) -> HGNN block -> bipartite head."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        self.hparams = dict(hparams)
+        self.ignn_block = InteractionGNNBlock(hparams, hparams["n_interaction_graph_iters"], emb=True)
+        self.hgnn_block = HierarchicalGNNBlock(hparams)
+        self.bipartite_output_layer = make_mlp(2 * hparams["latent"], hparams["hidden"], 1,
+                                               hparams["output_layers"], layer_norm=hparams["layernorm"],
+                                               output_activation=None,
+                                               hidden_activation=hparams["hidden_output_activation"])
+
+    def embed(self, x, graph):
+        """HGNN_GMM.py:328-331: returns (directed_graph, embeddings[N,emb_dim], nodes, edges)"""
+        directed_graph = torch.cat([graph, graph.flip(0)], dim=1)
+        emb, nodes, edges = self.ignn_block(x, directed_graph)
+        return directed_graph, emb, nodes, edges
+
+    def score(self, nodes, supernodes, bipartite_graph):
+        """HGNN_GMM.py:342-344"""
+        s = concat_mlp(self.bipartite_output_layer,
+                       [(nodes, bipartite_graph[0]), (supernodes, bipartite_graph[1])]).squeeze(-1)
+        return torch.sigmoid(s)

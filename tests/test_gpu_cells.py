@@ -115,3 +115,43 @@ def test_torch_scatter_shim_resolves_to_hip():
     finally:
         sys.path.pop(0)
         sys.modules.pop("torch_scatter", None)
+
+
+def test_bc_hgnn_message_passing_against_reference_forward():
+    """BASELINE config 3 arithmetic at small latent: IGNN block, K5 pooling + encoders (a8),
+    HGNN cell loop and the bipartite head reproduce the tensors captured inside the
+    reference's BC_HierarchicalGNN_GMM.forward (the hierarchy itself is taken from the capture)."""
+    from hierarchicalgnn_amd.models import BC_MessagePassing
+    z = load_golden("bc_hgnn_L32.npz")
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    model = BC_MessagePassing(hp)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing
+    assert all(("graph_construction" in k) or k.endswith("score_cut") for k in unexpected), unexpected
+    model = model.cuda().eval()
+    x = torch.from_numpy(z["x"]).cuda()
+    graph = torch.from_numpy(z["edge_index"]).cuda()
+    t = lambda k: torch.from_numpy(z[k]).cuda()
+    with torch.no_grad():
+        directed, emb, nodes, edges = model.embed(x, graph)
+        assert rel_err(emb.cpu().numpy(), z["embeddings"]) <= TOL
+        assert rel_err(nodes.cpu().numpy(), z["cell0.in.nodes"]) <= TOL
+        assert rel_err(edges.cpu().numpy(), z["cell0.in.edges"]) <= TOL
+        means = t("cell0.in.supernodes")[:, :hp["emb_dim"]].contiguous()
+        bg, bw = t("cell0.in.bipartite_graph"), t("cell0.in.bipartite_edge_weights")
+        sg, sw = t("cell0.in.super_graph"), t("cell0.in.super_edge_weights")
+        # a8: pooled + encoded supernodes / superedges as they enter the first cell
+        blk = model.hgnn_block
+        from hierarchicalgnn_amd import gather_scale_scatter, l1_row_scale
+        pooled = gather_scale_scatter(nodes, bg[0], bg[1], means.shape[0], bw, row_scale=l1_row_scale(nodes))
+        sn0 = torch.cat([means, blk._encode_supernodes(pooled)], dim=-1)
+        assert rel_err(sn0.cpu().numpy(), z["cell0.in.supernodes"]) <= TOL
+        se0 = blk._encode_superedges(sn0, sg)
+        assert rel_err(se0.cpu().numpy(), z["cell0.in.superedges"]) <= TOL
+        n_out, sn_out, e_out, se_out = blk(nodes, edges, directed, means, bg, bw, sg, sw)
+        last = int(z["n_cells"]) - 1
+        assert rel_err(n_out.cpu().numpy(), z[f"cell{last}.out.nodes"]) <= TOL
+        assert rel_err(sn_out.cpu().numpy(), z[f"cell{last}.out.supernodes"]) <= TOL
+        scores = model.score(n_out, sn_out, t("bipartite_graph"))
+        assert np.abs(scores.cpu().numpy() - z["bipartite_scores"]).max() <= 1e-4

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""End-to-end inference forward of the flat EC-IN model (BASELINE config 2: latent=128, 14 cells)
+on the synthetic TrackML-shaped event, fused kernels vs library path.  Usage: bench_model.py [L]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hierarchicalgnn_amd import fused, synth
+from hierarchicalgnn_amd.models import EC_InteractionGNN
+
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+torch.manual_seed(1236)
+hp = dict(spatial_channels=3, latent=L, hidden=2 * L, n_interaction_graph_iters=14, nb_node_layer=3,
+          nb_edge_layer=2, output_layers=3, hidden_output_activation="GELU", hidden_activation="GELU",
+          layernorm=True, share_weight=False)
+model = EC_InteractionGNN(hp).cuda().eval()
+x, ei = synth.trackml_event()
+x, ei = x.cuda(), ei.cuda()
+res = {"model": "EC-IN", "latent": L, "cells": 14, "N": x.shape[0], "E": ei.shape[1],
+       "params": sum(p.numel() for p in model.parameters())}
+M = 2 * ei.shape[1]
+flop = 14 * (2 * (3 * L * 2 * L + 2 * L * L) * M + 2 * (2 * L * 2 * L + 4 * L * L + 2 * L * L) * x.shape[0])
+outs = {}
+with torch.no_grad():
+    for name, on in (("fused", True), ("library", False)):
+        fused.set_enabled(on)
+        for _ in range(2):
+            s = model(x, ei)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            s = model(x, ei)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        ts.sort()
+        res[f"forward_{name}_ms"] = ts[len(ts) // 2]
+        res[f"cells_{name}_tflops"] = flop / ts[len(ts) // 2] / 1e9
+        outs[name] = s
+    fused.set_enabled(True)
+res["max_abs_score_diff_fused_vs_library"] = float((outs["fused"] - outs["library"]).abs().max())
+res["edges_scored_per_s_fused"] = ei.shape[1] / res["forward_fused_ms"] * 1e3
+print(json.dumps(res, indent=1))
