@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID = 0, 1, 2, 3, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HgnnPlan(Structure):
@@ -62,6 +62,8 @@ _SIGNATURES = {
     "hgnn_edge_dot_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                   c_int64, c_void_p, c_void_p]),
     "hgnn_index_to_i32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "hgnn_knn_radius_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p,
+                                    c_void_p, c_void_p]),
     "hgnn_mlp_supported": (c_int, [POINTER(HgnnMlpDesc)]),
     "hgnn_mlp_forward_f32": (c_int, [POINTER(HgnnMlpDesc), c_void_p, c_void_p]),
 }

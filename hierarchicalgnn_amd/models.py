@@ -116,8 +116,32 @@ class HierarchicalGNNBlock(nn.Module):
         else:
             cells = [HierarchicalGNNCell(hparams) for _ in range(n)]
         self.hgnn_cells = nn.ModuleList(cells)
+        # same names / buffers as the reference block (HGNN_GMM.py:155-157) so that its
+        # state_dict loads strictly; `score_cut` belongs to the (host-side) GMM edge cut
+        from .graph_construction import DynamicGraphConstruction
+        self.super_graph_construction = DynamicGraphConstruction("sigmoid", hparams)
+        self.bipartite_graph_construction = DynamicGraphConstruction("exp", hparams)
+        self.register_buffer("score_cut", torch.tensor([float("inf")]))
         self.hparams = hparams
         self._ckpt = bool(hparams.get("checkpointing", True))
+
+    def hierarchy_from_clusters(self, embeddings, clusters):
+        """HGNN_GMM.py:251-260 given the cluster label of every hit (-1 = unclustered): centroids
+        (scatter_mean, K8), L2-normalise, kNN super graph (symmetrised, sigmoid weights) and
+        bipartite graph (exp weights), both mean-normalised."""
+        from .ops import scatter_add
+        mask = clusters >= 0
+        n_clusters = int(clusters.max().item()) + 1
+        emb_c, lab_c = embeddings[mask], clusters[mask].contiguous()
+        sums = scatter_add(emb_c, lab_c, dim=0, dim_size=n_clusters)
+        counts = scatter_add(torch.ones(emb_c.shape[0], 1, device=emb_c.device), lab_c, dim=0,
+                             dim_size=n_clusters).clamp_(min=1)
+        means = nn.functional.normalize(sums / counts)
+        super_graph, super_w = self.super_graph_construction(
+            means, means, sym=True, norm=True, k=self.hparams["supergraph_sparsity"])
+        bip_graph, bip_w, bip_logits = self.bipartite_graph_construction(
+            embeddings, means, sym=False, norm=True, k=self.hparams["bipartitegraph_sparsity"], logits=True)
+        return means, bip_graph, bip_w, super_graph, super_w, bip_logits
 
     def _encode_supernodes(self, pooled):
         return concat_mlp(self.supernode_encoder, [(pooled, None)])

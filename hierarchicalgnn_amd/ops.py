@@ -253,3 +253,56 @@ def gather_rows(table: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
 def l1_row_scale(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     """1 / max(||x_i||_1, eps): the per-row factor of F.normalize(x, p=1) (HGNN_GMM.py:269)"""
     return 1.0 / x.abs().sum(dim=1).clamp_min(eps)
+
+
+# --------------------------------------------------------------------------- K11 per-edge dot products
+class _EdgeDot(torch.autograd.Function):
+    """out[e] = <A[ai[e]], B[bi[e]]>  (torch.einsum('ij,ij->i', A[ai], B[bi]), gnn_utils.py:208)"""
+
+    @staticmethod
+    def forward(ctx, A, B, ai, bi):
+        from .plan import get_index32
+        A_c, B_c = A.contiguous(), B.contiguous()
+        ctx.save_for_backward(A_c, B_c)
+        ctx.idx = (ai, bi)
+        return _edge_dot(A_c, get_index32(ai, A_c.shape[0]), B_c, get_index32(bi, B_c.shape[0]), int(ai.numel()))
+
+    @staticmethod
+    def backward(ctx, g):
+        A_c, B_c = ctx.saved_tensors
+        ai, bi = ctx.idx
+        g_c = g.contiguous()
+        grad_A = grad_B = None
+        if ctx.needs_input_grad[0]:   # dA[a] = sum_{e: ai[e]=a} g[e] * B[bi[e]]
+            grad_A = _seg_reduce(get_plan(ai, int(A_c.shape[0]), bi, int(B_c.shape[0])), B_c, g_c, None)
+        if ctx.needs_input_grad[1]:
+            grad_B = _seg_reduce(get_plan(bi, int(B_c.shape[0]), ai, int(A_c.shape[0])), A_c, g_c, None)
+        return grad_A, grad_B, None, None
+
+
+def edge_dot(A: torch.Tensor, ai: torch.Tensor, B: torch.Tensor, bi: torch.Tensor) -> torch.Tensor:
+    """per-edge dot product of two gathered rows without materialising the gathers; differentiable"""
+    _require_hip(A, "A")
+    _require_hip(B, "B")
+    if A.dim() != 2 or B.dim() != 2 or A.shape[1] != B.shape[1] or ai.shape != bi.shape or ai.dim() != 1:
+        raise RuntimeError("edge_dot: A[*,F], B[*,F] and 1-D index tensors of equal length expected")
+    return _EdgeDot.apply(A, B, ai, bi)
+
+
+def knn_radius(query: torch.Tensor, points: torch.Tensor, k: int, radius: float, return_dist2: bool = False):
+    """<=k nearest `points` of every `query` row with squared distance < radius^2, ascending,
+    -1 padded: the idxs of frnn.frnn_grid_points (Modules/utils.py:232) for one batch."""
+    _require_hip(query, "query")
+    _require_hip(points, "points")
+    if query.dim() != 2 or points.dim() != 2 or query.shape[1] != points.shape[1]:
+        raise RuntimeError("knn_radius: query[N,D] and points[S,D] expected")
+    q, p = query.detach().contiguous(), points.detach().contiguous()
+    nq, D = int(q.shape[0]), int(q.shape[1])
+    idx = torch.empty((nq, int(k)), dtype=torch.int64, device=q.device)
+    d2 = torch.empty((nq, int(k)), dtype=torch.float32, device=q.device) if return_dist2 else None
+    lib = _lib.load()
+    with torch.cuda.device(q.device):
+        _lib.check(lib.hgnn_knn_radius_f32(_lib.ptr(q), nq, _lib.ptr(p), int(p.shape[0]), D, int(k),
+                                           ctypes.c_float(float(radius)), _lib.ptr(idx), _lib.ptr(d2),
+                                           _lib.current_stream(q.device)), "hgnn_knn_radius_f32")
+    return (idx, d2) if return_dist2 else idx

@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 3
+#define HGNN_ABI_VERSION 4
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -149,6 +149,14 @@ int hgnn_edge_dot_f32(const float* A, const int32_t* ai, int64_t a_rows,
 /* int64 -> int32 index conversion with range check (out-of-range -> -1, err flag set) */
 int hgnn_index_to_i32(const int64_t* idx, int64_t M, int64_t limit, int32_t* out,
                       int32_t* err_flag, hgnn_stream_t stream);
+
+/* Fixed-radius kNN (exact, tiled brute force) in a D<=16 dimensional space: for every query
+ * the <=K nearest points with squared distance < radius^2, ascending (ties: lower index first),
+ * idx -1 padded; dist2_out (may be NULL) holds squared distances, -1 for padding.
+ * Replaces frnn.frnn_grid_points as called by find_neighbors (Modules/utils.py:228-239) from
+ * DynamicGraphConstruction.forward (Modules/gnn_utils.py:194).  K in {1-6,8,10,12,16,20,32}. */
+int hgnn_knn_radius_f32(const float* query, int64_t nq, const float* points, int64_t np, int32_t D,
+                        int32_t K, float radius, int64_t* idx_out, float* dist2_out, hgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused gather -> concat -> Linear -> LayerNorm -> act -> ... -> (+skip) MLP

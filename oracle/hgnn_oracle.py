@@ -183,3 +183,44 @@ def scatter_add_cpu_timed(src: Tensor, index: Tensor, dim_size: int, reps: int =
         out = torch.zeros(dim_size, src.shape[1], dtype=src.dtype).scatter_add_(0, idx, src)
         best = min(best, time.perf_counter() - t0)
     return best, out
+
+
+# ---------------------------------------------------------------------------
+# kNN graph rebuild + attention weights  [Modules/gnn_utils.py:183-218, Modules/utils.py:228-239]
+#
+# frnn 0.0.0 (reference README.md:45) and cugraph 22.04 (README.md:42) are un-vendored and
+# absent here: "parity unpinned" for WHICH edges/ordering those libraries return.  The
+# restatement below follows their documented contracts (frnn_grid_points: the K nearest points
+# within radius r, sorted by distance, idx -1 padded; symmetrize: union of both directions
+# without duplicates).  The weight arithmetic (:208-214) IS pinned: the golden BC-HGNN fixture
+# holds the reference's own outputs for it on a captured graph.
+# ---------------------------------------------------------------------------
+def knn_radius(query: Tensor, points: Tensor, k: int, radius: float):
+    d2 = torch.zeros(query.shape[0], points.shape[0], dtype=query.dtype)
+    for d in range(query.shape[1]):                       # same accumulation order as the kernel
+        t = query[:, d:d + 1] - points[:, d].unsqueeze(0)
+        d2 = d2 + t * t
+    kk = min(k, points.shape[0])
+    order = torch.argsort(d2, dim=1, stable=True)[:, :kk]
+    dist = torch.gather(d2, 1, order)
+    idx = torch.where(dist < radius * radius, order, torch.full_like(order, -1))
+    dist = torch.where(idx >= 0, dist, torch.full_like(dist, -1.0))
+    if kk < k:
+        idx = torch.cat([idx, torch.full((idx.shape[0], k - kk), -1, dtype=idx.dtype)], 1)
+        dist = torch.cat([dist, torch.full((dist.shape[0], k - kk), -1.0, dtype=dist.dtype)], 1)
+    return idx, dist
+
+
+def graph_edge_weights(src_emb, dst_emb, graph, bn_weight, bn_bias, bn_mean, bn_var, weighting: str,
+                       norm: bool, training: bool = False, eps: float = 1e-5):
+    """gnn_utils.py:208-214 with BatchNorm1d(1) written out"""
+    likelihood = (src_emb[graph[0]] * dst_emb[graph[1]]).sum(-1)
+    if training:
+        mean, var = likelihood.mean(), likelihood.var(unbiased=False)
+    else:
+        mean, var = bn_mean, bn_var
+    logits = (likelihood - mean) / torch.sqrt(var + eps) * bn_weight + bn_bias
+    w = torch.exp(logits) if weighting == "exp" else torch.sigmoid(logits)
+    if norm:
+        w = w / w.mean()
+    return w.unsqueeze(1), logits

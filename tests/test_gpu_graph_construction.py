@@ -1,0 +1,114 @@
+"""GPU parity of the kNN graph rebuild + attention weights:
+DynamicGraphConstruction (gnn_utils.py:171-218), find_neighbors (utils.py:228-239)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("nq,np_,D,K,r", [(500, 300, 8, 5, 0.9), (300, 300, 8, 10, 0.6), (100, 7, 8, 10, 2.0),
+                                          (64, 1000, 3, 4, 0.2), (10, 50, 16, 1, 5.0)])
+def test_knn_radius_vs_oracle(nq, np_, D, K, r):
+    import hierarchicalgnn_amd as H
+    from hierarchicalgnn_amd.ops import knn_radius
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(nq + K)
+    q = torch.nn.functional.normalize(torch.randn(nq, D, generator=g))
+    p = torch.nn.functional.normalize(torch.randn(np_, D, generator=g))
+    idx_ref, d_ref = O.knn_radius(q, p, K, r)
+    idx, d2 = knn_radius(q.cuda(), p.cuda(), K, r, return_dist2=True)
+    idx, d2 = idx.cpu(), d2.cpu()
+    assert idx.shape == (nq, K)
+    assert torch.equal(idx >= 0, idx_ref >= 0)                       # same neighbour counts (radius cut)
+    assert rel_err(d2.numpy(), d_ref.numpy()) <= 1e-5                # same sorted distances
+    # same neighbours wherever consecutive distances are separated (fp near-ties may swap)
+    gap_ok = torch.ones_like(idx, dtype=torch.bool)
+    gap_ok[:, 1:] &= (d_ref[:, 1:] - d_ref[:, :-1]).abs() > 1e-5
+    gap_ok[:, :-1] &= (d_ref[:, 1:] - d_ref[:, :-1]).abs() > 1e-5
+    assert torch.equal(idx[gap_ok], idx_ref[gap_ok])
+
+
+def test_edge_weights_against_reference_capture():
+    """the weight arithmetic of DynamicGraphConstruction on the graph captured from the
+    reference's BC-HGNN-GMM forward (eval mode, reference BatchNorm statistics)"""
+    from hierarchicalgnn_amd.graph_construction import DynamicGraphConstruction
+    z = load_golden("bc_hgnn_L32.npz")
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    emb = torch.from_numpy(z["embeddings"]).cuda()
+    means = torch.from_numpy(z["cell0.in.supernodes"])[:, :hp["emb_dim"]].contiguous().cuda()
+    for name, fn, src, dst, gkey, wkey in (
+            ("bipartite_graph_construction", "exp", emb, means, "cell0.in.bipartite_graph", "cell0.in.bipartite_edge_weights"),
+            ("super_graph_construction", "sigmoid", means, means, "cell0.in.super_graph", "cell0.in.super_edge_weights")):
+        m = DynamicGraphConstruction(fn, hp)
+        pre = f"sd.hgnn_block.{name}."
+        m.load_state_dict({k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}, strict=True)
+        m = m.cuda().eval()
+        graph = torch.from_numpy(z[gkey]).cuda()
+        with torch.no_grad():
+            w = m.edge_weights(src, dst, graph, norm=True)
+        assert w.shape == z[wkey].shape
+        assert rel_err(w.cpu().numpy(), z[wkey]) <= TOL, name
+
+
+@pytest.mark.parametrize("sym,fn", [(False, "exp"), (True, "sigmoid")])
+def test_dynamic_graph_construction_train_mode_vs_oracle(sym, fn):
+    from hierarchicalgnn_amd.graph_construction import DynamicGraphConstruction
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(5)
+    n, s, k = 400, 40, 5
+    src = torch.nn.functional.normalize(torch.randn(n, 8, generator=g))
+    dst = torch.nn.functional.normalize(torch.randn(s, 8, generator=g))
+    if sym:
+        src = dst
+    m = DynamicGraphConstruction(fn, {}).cuda().train()
+    m.knn_radius.fill_(1.1)
+    a = src.cuda().requires_grad_(True)
+    b = a if sym else dst.cuda().requires_grad_(True)
+    graph, w, logits = m(a, b, sym=sym, norm=True, k=k, logits=True)
+    # oracle: same neighbours -> same graph (as a set), radius EMA, training-mode BatchNorm, weights, grads
+    idx, d2 = O.knn_radius(src, dst, k, 1.1)
+    pos = idx >= 0
+    ind = torch.arange(src.shape[0]).unsqueeze(1).expand(idx.shape)
+    s0, d0 = ind[pos], idx[pos]
+    if sym:
+        key = torch.unique(torch.cat([s0 * s + d0, d0 * s + s0]))
+        s0, d0 = key // s, key % s
+    ref_graph = torch.stack([s0, d0])
+    srt = lambda G: G[:, torch.argsort(G[0] * 100000 + G[1])]
+    gg = graph.cpu()
+    assert torch.equal(srt(gg), srt(ref_graph))
+    assert abs(float(m.knn_radius) - (0.9 * 1.1 + 0.11 * float(d2[pos].max().sqrt()))) < 1e-5
+    ar = src.clone().requires_grad_(True)
+    br = ar if sym else dst.clone().requires_grad_(True)
+    w_ref, logit_ref = O.graph_edge_weights(ar, br, gg, torch.ones(1), torch.zeros(1), None, None, fn, True,
+                                            training=True)
+    assert rel_err(w.detach().cpu().numpy(), w_ref.detach().numpy()) <= TOL
+    r = torch.randn(w.shape, generator=g)
+    (w * r.cuda()).sum().backward()
+    (w_ref * r).sum().backward()
+    assert rel_err(a.grad.cpu().numpy(), ar.grad.numpy()) <= 1e-3
+    if not sym:
+        assert rel_err(b.grad.cpu().numpy(), br.grad.numpy()) <= 1e-3
+
+
+def test_knn_full_size_bipartite_properties():
+    """N=120k hits -> S=10k centres, K=5 (BASELINE HGNN shape): every returned neighbour is within the
+    radius, lists are sorted, and a sample of queries matches the CPU oracle"""
+    from hierarchicalgnn_amd.ops import knn_radius
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(11)
+    q = torch.nn.functional.normalize(torch.randn(120_000, 8, generator=g))
+    p = torch.nn.functional.normalize(torch.randn(10_000, 8, generator=g))
+    idx, d2 = knn_radius(q.cuda(), p.cuda(), 5, 0.8, return_dist2=True)
+    idx, d2 = idx.cpu(), d2.cpu()
+    ok = idx >= 0
+    assert float(d2[ok].max()) < 0.8 * 0.8
+    dd = torch.where(ok, d2, torch.full_like(d2, 9.0))
+    assert bool((dd[:, 1:] >= dd[:, :-1]).all())
+    sel = torch.randint(0, 120_000, (200,), generator=g)
+    idx_ref, d_ref = O.knn_radius(q[sel], p, 5, 0.8)
+    assert rel_err(d2[sel].numpy(), d_ref.numpy()) <= 1e-5
