@@ -85,6 +85,9 @@ class HierarchicalGNNCell(nn.Module):
                                           hidden_activation=act)
         self.hparams = hparams
         self._ckpt = bool(hparams.get("checkpointing", True))
+        # multi-GPU hook (partition.py): combines the per-shard node->supernode sums (K3) of a
+        # node-partitioned event; None on a single GPU
+        self.node_message_reduce = None
 
     # gnn_utils.py:120-127  (K2 + K1)
     def _node_update(self, nodes, edges, supernodes, graph, bipartite_graph, bipartite_edge_weights):
@@ -103,6 +106,8 @@ class HierarchicalGNNCell(nn.Module):
                           super_graph, super_edge_weights):
         node_messages = gather_scale_scatter(nodes, bipartite_graph[0], bipartite_graph[1],
                                              supernodes.shape[0], bipartite_edge_weights)
+        if self.node_message_reduce is not None:
+            node_messages = self.node_message_reduce(node_messages)
         attention_messages = scatter_add(superedges, super_graph[1], dim=0, dim_size=supernodes.shape[0],
                                          weight=super_edge_weights)
         return concat_mlp(self.supernode_network,

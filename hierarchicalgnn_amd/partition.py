@@ -243,21 +243,59 @@ def distributed_cell_forward(cell, halo: HaloExchange, nodes_owned, edges_local,
     return nodes_owned, edges_local
 
 
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of x (replicated result).  Every rank then runs the same replicated
+    computation on y but contributes its own local loss terms, so dL/dx_q = sum_r dL_r/dy_r:
+    the backward is again an all_reduce(SUM)."""
+
+    @staticmethod
+    def forward(ctx, t, group):
+        import torch.distributed as dist
+        ctx.group = group
+        out = t.clone()
+        dist.all_reduce(out, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        g = g.contiguous().clone()
+        dist.all_reduce(g, group=ctx.group)
+        return g, None
+
+
 def allreduce_supernode_sums(partial: torch.Tensor, group=None) -> torch.Tensor:
     """K3/K5 across shards: each rank sums its owned hits into the replicated [S,L]
     supernode table; one all_reduce combines them."""
-    import torch.distributed as dist
+    return _AllReduceSum.apply(partial, group)
 
-    class _AR(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, t):
-            out = t.clone()
-            dist.all_reduce(out, group=group)
-            return out
 
-        @staticmethod
-        def backward(ctx, g):
-            # every rank holds the same downstream gradient of the replicated sum
-            return g
+def shard_bipartite(shard: EventShard, bipartite_graph: torch.Tensor, bipartite_edge_weights: torch.Tensor):
+    """keep the bipartite edges whose hit this rank owns; hit ids become local, supernode ids
+    stay global (supernodes are replicated).  Returns (graph[2,B_p], weights[B_p,1], selection)."""
+    g2l = torch.full((shard.n_global,), -1, dtype=torch.long)
+    g2l[shard.owned_global] = torch.arange(shard.n_owned)
+    loc = g2l[bipartite_graph[0]]
+    sel = torch.nonzero(loc >= 0).squeeze(1)
+    return torch.stack([loc[sel], bipartite_graph[1][sel]]).contiguous(), bipartite_edge_weights[sel], sel
 
-    return _AR.apply(partial)
+
+def distributed_hgnn_cell_forward(cell, halo: HaloExchange, nodes_owned, edges_local, supernodes, superedges,
+                                  local_graph, bipartite_local, bipartite_w_local, super_graph, super_w, group=None):
+    """HierarchicalGNNCell.forward (Modules/gnn_utils.py:155-169) on one shard.  Supernodes and
+    superedges are replicated (every rank computes their small updates redundantly); the only
+    collectives are the all_reduce of the node->supernode sums and the halo exchange before the
+    edge update.  Gradients of the replicated parameters must be summed over ranks (as DDP does)."""
+    prev = getattr(cell, "node_message_reduce", None)
+    cell.node_message_reduce = lambda t: allreduce_supernode_sums(t, group)
+    try:
+        supernodes = cell.supernode_update(nodes_owned, supernodes, superedges, bipartite_local,
+                                           bipartite_w_local, super_graph, super_w)
+    finally:
+        cell.node_message_reduce = prev
+    nodes_owned = cell.node_update(nodes_owned, edges_local, supernodes, local_graph, bipartite_local,
+                                   bipartite_w_local)
+    superedges = cell.superedge_update(supernodes, superedges, super_graph, super_w)
+    nodes_ext = halo.extend(nodes_owned)
+    edges_local = cell.edge_update(nodes_ext, edges_local, local_graph)
+    return nodes_owned, edges_local, supernodes, superedges

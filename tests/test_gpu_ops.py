@@ -305,3 +305,32 @@ def test_full_size_supernode_pooling_skew(H, O):
     ref = O.scatter_add(w * X[bg[0]], bg[1], 0, 10_000)
     out = H.gather_scale_scatter(X.cuda(), bg[0].cuda(), bg[1].cuda(), 10_000, w.cuda())
     assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
+
+
+def test_c_abi_is_graph_capturable(H):
+    """no allocation / host sync inside the launch functions: K1 + its backward kernel replay
+    from a captured HIP graph with new data"""
+    g = torch.Generator().manual_seed(12)
+    M, N, F = 20000, 700, 256
+    idx = torch.randint(0, N, (M,), generator=g).cuda()
+    plan = H.get_plan(idx, N)
+    src = torch.randn(M, F, generator=g).cuda()
+    gout = torch.randn(N, F, generator=g).cuda()
+    from hierarchicalgnn_amd.ops import _seg_reduce, _spread_rows
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        _seg_reduce(plan, src, None, None)
+        _spread_rows(plan, gout)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = _seg_reduce(plan, src, None, None)
+        back = _spread_rows(plan, gout)
+    src.copy_(torch.randn(M, F, generator=g))
+    gout.copy_(torch.randn(N, F, generator=g))
+    graph.replay()
+    torch.cuda.synchronize()
+    ref = torch.zeros(N, F, device="cuda").index_add_(0, idx, src)
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) <= TOL
+    assert torch.equal(back, gout[idx])

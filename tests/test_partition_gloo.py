@@ -135,3 +135,104 @@ def test_partition_is_balanced_and_local():
         assert s.n_halo < 0.5 * s.n_owned
     assert max(rows) / (sum(rows) / 4) < 1.05                    # edge-balanced
     assert sum(rows) == 2 * ei.shape[1]
+
+
+# ---------------------------------------------------------------- hierarchical cell on shards
+class _OracleHCell:
+    """CPU stand-in for HierarchicalGNNCell with the same update methods and reduce hook"""
+
+    def __init__(self, sd):
+        self.sd = sd
+        self.node_message_reduce = None
+
+    def supernode_update(self, nodes, supernodes, superedges, bg, bw, sg, sw):
+        node_msg = O.scatter_add(bw * nodes[bg[0]], bg[1], 0, supernodes.shape[0])
+        if self.node_message_reduce is not None:
+            node_msg = self.node_message_reduce(node_msg)
+        attn = O.scatter_add(superedges * sw, sg[1], 0, supernodes.shape[0])
+        inp = torch.cat([supernodes, attn, node_msg], -1)
+        return O.mlp_apply(self.sd, "supernode_network.", inp, 3, "GELU", "GELU", True) + supernodes
+
+    def node_update(self, nodes, edges, supernodes, graph, bg, bw):
+        return O.hgnn_node_update(self.sd, "", HP, nodes, edges, supernodes, graph, bg, bw)
+
+    def superedge_update(self, supernodes, superedges, sg, sw):
+        return O.edge_update(self.sd, "", HP, supernodes, superedges, sg, net="superedge_network.")
+
+    def edge_update(self, nodes, edges, graph):
+        return O.edge_update(self.sd, "", HP, nodes, edges, graph)
+
+
+def _make_hproblem():
+    from hierarchicalgnn_amd import HierarchicalGNNCell
+    torch.manual_seed(0)
+    x, ei = synth.trackml_event(400, 2000, seed=4)
+    graph = synth.directed(ei)
+    cell = HierarchicalGNNCell(HP)
+    sd = {k: v.detach().clone() for k, v in cell.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    S = 11
+    bg, bw = synth.bipartite_assignment(400, S, 3, seed=6)
+    sg, sw = synth.super_graph(S, 3, seed=6)
+    t = dict(nodes=torch.randn(400, 16, generator=g), edges=torch.randn(graph.shape[1], 16, generator=g),
+             sn=torch.randn(S, 16, generator=g), se=torch.randn(sg.shape[1], 16, generator=g))
+    r = {k: torch.randn(v.shape, generator=g) for k, v in t.items()}
+    return x, ei, graph, sd, bg, bw, sg, sw, t, r
+
+
+def _hworker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        x, ei, graph, sd, bg, bw, sg, sw, t, r = _make_hproblem()
+        shard = partition.partition_event(x, ei, world, rank)
+        halo = partition.HaloExchange(shard, "cpu", mode="all_to_all")
+        bgl, bwl, bsel = partition.shard_bipartite(shard, bg, bw)
+        n_loc = t["nodes"][shard.owned_global].clone().requires_grad_(True)
+        e_loc = t["edges"][shard.edge_global].clone().requires_grad_(True)
+        sn = t["sn"].clone().requires_grad_(True)
+        se = t["se"].clone().requires_grad_(True)
+        on, oe, osn, ose = partition.distributed_hgnn_cell_forward(
+            _OracleHCell(sd), halo, n_loc, e_loc, sn, se, shard.local_graph, bgl, bwl, sg, sw)
+        # local terms once per owner, replicated terms split evenly: the ranks' losses sum to the global loss
+        loss = (on * r["nodes"][shard.owned_global]).sum() + (oe * r["edges"][shard.edge_global]).sum() \
+            + ((osn * r["sn"]).sum() + (ose * r["se"]).sum()) / world
+        loss.backward()
+        q.put((rank, shard.owned_global, shard.edge_global, on.detach(), oe.detach(), osn.detach(), ose.detach(),
+               n_loc.grad.clone(), e_loc.grad.clone(), sn.grad.clone(), se.grad.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partitioned_hierarchical_cell_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hworker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, ei, graph, sd, bg, bw, sg, sw, t, r = _make_hproblem()
+    ref_in = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    on, oe, osn, ose = O.hgnn_cell(sd, "", HP, ref_in["nodes"], ref_in["edges"], ref_in["sn"], ref_in["se"],
+                                   graph, bg, bw, sg, sw)
+    ((on * r["nodes"]).sum() + (oe * r["edges"]).sum() + (osn * r["sn"]).sum() + (ose * r["se"]).sum()).backward()
+    g_sn = torch.zeros_like(t["sn"])
+    g_se = torch.zeros_like(t["se"])
+    for rank, owned, eglob, a, b, c, d, gn, ge, gsn, gse in results:
+        assert torch.allclose(a, on.detach()[owned], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(b, oe.detach()[eglob], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(c, osn.detach(), rtol=1e-5, atol=1e-6)      # replicated, identical everywhere
+        assert torch.allclose(d, ose.detach(), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(gn, ref_in["nodes"].grad[owned], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(ge, ref_in["edges"].grad[eglob], rtol=1e-4, atol=1e-5)
+        g_sn += gsn
+        g_se += gse
+    assert torch.allclose(g_sn, ref_in["sn"].grad, rtol=1e-4, atol=1e-5)    # replicated inputs: grads sum over ranks
+    assert torch.allclose(g_se, ref_in["se"].grad, rtol=1e-4, atol=1e-5)
