@@ -31,6 +31,9 @@ namespace hgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+static int g_opt_mlp_stagger = 0;
+static int g_opt_mlp_ablate = 0;
+
 struct MlpArgs {
     const float* seg_table[3];
     const int32_t* seg_index[3];
@@ -46,40 +49,112 @@ struct MlpArgs {
     const float* skip;
     float* out;
     long long M;
+    int ablate;        // DIAGNOSTIC ONLY (wrong results): 1 = skip LN/act, 2 = skip weight DMA, 4 = skip barriers
+    int stagger;       // one-time start delay (x s_sleep 127) of the second resident workgroup per CU
+    int stagger_from;  // first block index that is delayed (= number of CUs)
 };
+
+// Activations.  v_mfma_f32_16x16x4_f32 runs on the SIMD's fp32 vector ALUs (its rate IS the VALU FMA
+// rate), so epilogue VALU work does not hide under a co-resident wave's MFMAs: every VALU
+// instruction here is paid in full (ablation: LayerNorm+act were 15.7 % of the kernel with libm
+// erff/tanhf).  Hence branch-free forms built on v_exp_f32 / v_rcp_f32:
+//   erf : Abramowitz-Stegun 7.1.26, |abs error| <= 1.5e-7  (exact-GELU parity bar is 1e-4 rel)
+//   tanh: 1 - 2/(exp(2|x|)+1), abs error ~1e-7
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * ax * ax);
+    const float r = fmaf(-p, e, 1.0f);
+    return __builtin_copysignf(r, x);
+}
+
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(2.88539008177792681f * ax);  // exp(2|x|)
+    const float r = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+    return __builtin_copysignf(r, x);
+}
 
 __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
-        case HGNN_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-        case HGNN_ACT_TANH: return tanhf(x);
+        case HGNN_ACT_GELU: return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+        case HGNN_ACT_TANH: return fast_tanh(x);
         case HGNN_ACT_RELU: return x > 0.f ? x : 0.f;
         default: return x;
     }
 }
 
-// stage rows [0, NF) x columns [k0, k0+16) of W[NF][Kdim] into lds, one 1-KiB piece per 16 rows,
-// each piece in A-fragment order [g = k/4][i = row][4 floats]
+// Weight staging.  W[NF][Kdim] row-major (torch Linear.weight); chunk = columns [k0, k0+16).
+// One 1-KiB LDS-DMA piece covers 16 rows: lane (i = lane&15, g = lane>>4) fetches
+// W[16p+i][k0+4g .. +3] and the DMA lands it at lane*16 bytes, i.e. the piece is stored in exactly
+// the order the MFMA A-fragment read (ds_read_b128 at lane*16) wants: conflict-free, no swizzle.
+// Address = wave-uniform piece base (SALU) + a fixed 32-bit per-lane byte offset.
+// A tiny state machine so that only ONE per-lane 64-bit source pointer and one scalar LDS address
+// stay live across the MFMA loop (eight precomputed piece addresses cost 16 VGPRs and pushed the
+// L=256 kernel into scratch).
+struct WStage {
+    const char* src;        // per-lane source of the NEXT piece to issue
+    unsigned lds;           // LDS byte address of the NEXT piece's destination (wave-uniform)
+    unsigned piece_stride;  // bytes between this wave's consecutive pieces in W (64 rows)
+};
+
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Issued as inline asm on purpose: hipcc orders every later ds_read behind a builtin LDS-DMA with
+// s_waitcnt vmcnt(0) (it cannot see that the DMA fills the OTHER buffer), which would serialise
+// each piece's memory latency into the MFMA loop.  The hand-off is done by hand instead: every wave
+// drains its DMAs (wait_dma) right before the barrier that publishes them.
+__device__ __forceinline__ void dma_piece(const char* src, unsigned lds_addr) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(src), "s"(lds_addr)
+        : "memory", "m0");
+}
+
+__device__ __forceinline__ unsigned lds_addr_of(float* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) float*)p;
+}
+
+// start staging chunk k0 of W[NF][Kdim] into `lds`: points at this wave's first piece
+__device__ __forceinline__ WStage begin_stage(const float* W, int Kdim, int k0, float* lds, int wave, int lane) {
+    WStage st;
+    st.src = (const char*)(W + (size_t)(wave * 16 + (lane & 15)) * (size_t)Kdim + k0 + (lane >> 4) * 4);
+    st.lds = lds_addr_of(lds) + (unsigned)wave * 1024u;
+    st.piece_stride = (unsigned)(64 * Kdim * (int)sizeof(float));
+    return st;
+}
+
+__device__ __forceinline__ void stage_next(WStage& st) {
+    dma_piece(st.src, st.lds);
+    st.src += st.piece_stride;
+    st.lds += 4096u;  // 4 pieces further
+}
+
+// number of pieces wave `wave` owns of an NF-row chunk (pieces p = wave, wave+4, ...)
+template <int NF>
+__device__ __forceinline__ int pieces_of(int wave) {
+    constexpr int PIECES = NF / 16;
+    return PIECES % 4 == 0 ? PIECES / 4 : (PIECES / 4 + (wave < PIECES % 4 ? 1 : 0));
+}
+
 template <int NF>
 __device__ __forceinline__ void stage_w(const float* __restrict__ W, int Kdim, int k0, float* lds,
                                         int wave, int lane) {
-    constexpr int PIECES = NF / 16;  // 1 KiB each
-    constexpr int PER_WAVE = (PIECES + 3) / 4;
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const int p = i * 4 + wave;  // wave is wave-uniform (SGPR): a scalar branch, no exec masking
-        if (PIECES % 4 != 0 && p >= PIECES) break;
-        // lane (i = lane&15, g = lane>>4) fetches W[16p+i][k0+4g .. +3]; the DMA lands it at
-        // lane*16 bytes, i.e. the piece is stored in exactly the order the MFMA A-fragment read
-        // (ds_read_b128 at lane*16) wants: conflict-free, no swizzle needed.
-        const float* src = W + (size_t)(p * 16 + (lane & 15)) * (size_t)Kdim + k0 + (lane >> 4) * 4;
-        float* dst = lds + p * 256;  // wave-uniform base; the DMA adds lane*16 bytes
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
+    WStage st = begin_stage(W, Kdim, k0, lds, wave, lane);
+    const int n = pieces_of<NF>(wave);
+    for (int i = 0; i < n; ++i) stage_next(st);
 }
 
 // acc[T][r] (edge = lane&15, feature = 16T + 4*(lane>>4) + r): LayerNorm over features, then act
-template <int NT>
+template <int NT, int ACT>
 __device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT], const float* __restrict__ lnw,
                                               const float* __restrict__ lnb, int act, float eps, int g) {
     constexpr float inv_n = 1.0f / (float)(NT * 16);
@@ -103,10 +178,11 @@ __device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT], const float* __r
         const f32x4 w4 = *(const f32x4*)(lnw + T * 16 + g * 4);
         const f32x4 b4 = *(const f32x4*)(lnb + T * 16 + g * 4);
         f32x4 v = (acc[T] - mean) * rstd * w4 + b4;
-        v.x = act_apply(v.x, act);
-        v.y = act_apply(v.y, act);
-        v.z = act_apply(v.z, act);
-        v.w = act_apply(v.w, act);
+        const int code = ACT >= 0 ? ACT : act;  // compile-time for the common networks
+        v.x = act_apply(v.x, code);
+        v.y = act_apply(v.y, code);
+        v.z = act_apply(v.z, code);
+        v.w = act_apply(v.w, code);
         acc[T] = v;
     }
 }
@@ -121,19 +197,30 @@ __device__ __forceinline__ void init_bias(f32x4 (&acc)[NT], const float* __restr
 // Tiles are processed in pairs (two independent accumulators cover the 40-cycle dependent-issue
 // latency of v_mfma_f32_16x16x4_f32) and the NEXT pair's weight fragments are fetched from LDS
 // before the current pair's 8 MFMAs, pinned with sched_group_barrier so that hipcc does not
-// sink the reads back to their first use (it did: every 8 MFMAs waited on an lgkmcnt(0)).
-template <int NT>
-__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[NT], const float* __restrict__ wb, const f32x4 b) {
+// sink the reads back to their first use.  The LDS-DMA pieces that stage the NEXT chunk's weights
+// are issued one at a time BETWEEN MFMA groups (each costs the issuing wave ~60 cycles of VMEM
+// issue; in a burst ahead of the loop they were 10 % of the kernel, in the MFMA shadow they hide).
+template <int NT, int NF_NEXT>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[NT], const float* __restrict__ wb, const f32x4 b,
+                                          WStage& st, int n_pieces) {
     static_assert(NT % 2 == 0, "tiles are processed in pairs");
+    constexpr int PAIRS = NT / 2;
+    constexpr int PER_WAVE = (NF_NEXT / 16 + 3) / 4;
+    constexpr int EVERY = PAIRS >= PER_WAVE ? PAIRS / PER_WAVE : 1;
     f32x4 w0 = *(const f32x4*)(wb);
     f32x4 w1 = *(const f32x4*)(wb + 256);
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // pipeline prologue: the first pair's reads
+    int issued = 0;
 #pragma unroll
     for (int T = 0; T < NT; T += 2) {
         f32x4 n0 = w0, n1 = w1;
         if (T + 2 < NT) {
             n0 = *(const f32x4*)(wb + (T + 2) * 256);
             n1 = *(const f32x4*)(wb + (T + 3) * 256);
+        }
+        if (((T / 2) % EVERY == 0) && issued < PER_WAVE) {
+            if (__builtin_amdgcn_readfirstlane(issued < n_pieces ? 1 : 0)) stage_next(st);  // scalar branch
+            ++issued;
         }
         acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, b.x, acc[T], 0, 0, 0);
         acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, b.x, acc[T + 1], 0, 0, 0);
@@ -148,21 +235,26 @@ __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[NT], const float* __restr
         if (T + 2 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads (next pair)
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                  // 8 MFMAs (this pair)
     }
+    for (int i = issued; i < n_pieces; ++i) stage_next(st);  // more pieces than tile pairs
 }
 
 // one register-resident layer: out[NTO tiles] = W[NTO*16][NTI*16] * in  (in = previous accumulators)
 template <int NTI, int NTO>
 __device__ __forceinline__ void dense_from_regs(const f32x4 (&in)[NTI], f32x4 (&out)[NTO],
-                                                const float* __restrict__ W, float* lds, int wave, int lane) {
+                                                const float* __restrict__ W, float* lds, int wave, int lane,
+                                                int ablate) {
     constexpr int KD = NTI * 16;
     constexpr int BUF = NTO * 256;  // floats per chunk buffer
+    const int n_pieces = pieces_of<NTO * 16>(wave);
     __syncthreads();                // everyone is done with both buffers of the previous layer
     stage_w<NTO * 16>(W, KD, 0, lds, wave, lane);
 #pragma unroll
     for (int c = 0; c < NTI; ++c) {
-        __syncthreads();  // chunk c landed (vmcnt(0) precedes the barrier); buffer (c+1)&1 is free
-        if (c + 1 < NTI) stage_w<NTO * 16>(W, KD, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
-        mma_chunk<NTO>(out, lds + (c & 1) * BUF + lane * 4, in[c]);
+        wait_dma();                           // this wave's pieces of chunk c have landed
+        if (!(ablate & 4)) __syncthreads();   // everyone's have; buffer (c+1)&1 is free again
+        const float* wb = lds + (c & 1) * BUF + lane * 4;
+        WStage st = begin_stage(W, KD, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
+        mma_chunk<NTO, NTO * 16>(out, wb, in[c], st, (c + 1 < NTI && !(ablate & 2)) ? n_pieces : 0);
     }
 }
 
@@ -183,7 +275,9 @@ __device__ __forceinline__ void store_out(const f32x4 (&acc)[NT], const MlpArgs&
 }
 
 // NT1/NT2/NT3: 16-feature tiles of layer 1 / 2 / 3 outputs (NT3 == 0: two-layer MLP)
-template <int NT1, int NT2, int NT3, int MINW>
+// ACT_H / ACT_O: activation of the hidden layers / of the last layer (HGNN_ACT_*), or -1 = read
+// it from the descriptor per element (keeps rare combinations working without an instantiation)
+template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O>
 __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -192,6 +286,16 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     const int g = lane >> 4;
     const long long e = (long long)blockIdx.x * 64 + wave * 16 + ei;
     const bool valid = e < a.M;
+    // Two workgroups share a CU.  Dispatched together they would run in lockstep: both in their
+    // MFMA loops, then both in their LayerNorm/GELU epilogues (matrix pipe idle).  Delaying the
+    // second wave of workgroups once, by about half a workgroup's lifetime, keeps one block's VALU
+    // epilogue under the other's MFMAs for the rest of the launch (speed only, never correctness).
+    if (a.stagger > 0 && (int)blockIdx.x < 2 * a.stagger_from) {
+        // HW_REG_HW_ID[3:0] = wave slot on this SIMD: co-resident waves differ in it (speed only)
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        if (slot & 1u)
+            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const long long er = valid ? e : 0;
 
     // per-lane row start of every input segment (the gather is folded in here).  The X stream is
@@ -232,45 +336,57 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     // ---------------- layer 1: K1 (runtime) -> NT1*16, weights through LDS, X from global
     f32x4 acc1[NT1];
     init_bias<NT1>(acc1, a.b[0], g);
+    __builtin_amdgcn_s_setprio(2);
     {
         constexpr int BUF = NT1 * 256;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         stage_w<NT1 * 16>(a.W[0], a.K1, 0, lds, wave, lane);
+        const int n_pieces = pieces_of<NT1 * 16>(wave);
         f32x4 x0 = next_x(zero);
         f32x4 x1 = next_x(zero);
         for (int c = 0; c < nc; ++c) {
-            __syncthreads();
-            if (c + 1 < nc) stage_w<NT1 * 16>(a.W[0], a.K1, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
+            wait_dma();
+            if (!(a.ablate & 4)) __syncthreads();
             const f32x4 x2 = next_x(zero);
-            mma_chunk<NT1>(acc1, lds + (c & 1) * BUF + lane * 4, x0);
+            const float* wb = lds + (c & 1) * BUF + lane * 4;
+            WStage st = begin_stage(a.W[0], a.K1, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
+            mma_chunk<NT1, NT1 * 16>(acc1, wb, x0, st, (c + 1 < nc && !(a.ablate & 2)) ? n_pieces : 0);
             x0 = x1;
             x1 = x2;
         }
     }
-    layernorm_act<NT1>(acc1, a.lnw[0], a.lnb[0], a.act[0], a.eps, g);
+    // Priority outranks age in the SIMD's issue arbitration: a wave in its (dense, wait-free) VALU
+    // epilogue would otherwise starve the co-resident workgroup's MFMA stream whenever it is the
+    // older of the two.  Epilogues run at priority 0, MFMA loops at priority 2.
+    __builtin_amdgcn_s_setprio(0);
+    if (!(a.ablate & 1)) layernorm_act<NT1, ACT_H>(acc1, a.lnw[0], a.lnb[0], a.act[0], a.eps, g);
+    __builtin_amdgcn_s_setprio(2);
 
     // ---------------- layer 2 (and 3): activations stay in registers
     f32x4 acc2[NT2];
     init_bias<NT2>(acc2, a.b[1], g);
-    dense_from_regs<NT1, NT2>(acc1, acc2, a.W[1], lds, wave, lane);
-    layernorm_act<NT2>(acc2, a.lnw[1], a.lnb[1], a.act[1], a.eps, g);
+    dense_from_regs<NT1, NT2>(acc1, acc2, a.W[1], lds, wave, lane, a.ablate);
+    __builtin_amdgcn_s_setprio(0);
+    if (!(a.ablate & 1)) layernorm_act<NT2, (NT3 == 0 ? ACT_O : ACT_H)>(acc2, a.lnw[1], a.lnb[1], a.act[1], a.eps, g);
     if constexpr (NT3 == 0) {
         store_out<NT2>(acc2, a, e, valid, g);
     } else {
         f32x4 acc3[NT3];
         init_bias<NT3>(acc3, a.b[2], g);
-        dense_from_regs<NT2, NT3>(acc2, acc3, a.W[2], lds, wave, lane);
-        layernorm_act<NT3>(acc3, a.lnw[2], a.lnb[2], a.act[2], a.eps, g);
+        __builtin_amdgcn_s_setprio(2);
+        dense_from_regs<NT2, NT3>(acc2, acc3, a.W[2], lds, wave, lane, a.ablate);
+        __builtin_amdgcn_s_setprio(0);
+        if (!(a.ablate & 1)) layernorm_act<NT3, ACT_O>(acc3, a.lnw[2], a.lnb[2], a.act[2], a.eps, g);
         store_out<NT3>(acc3, a, e, valid, g);
     }
 }
 
-template <int NT1, int NT2, int NT3, int MINW>
-static int launch_mlp(const MlpArgs& a, hipStream_t s) {
+template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O>
+static int launch_mlp_act(const MlpArgs& a, hipStream_t s) {
     constexpr int maxnt = NT1 > NT2 ? (NT1 > NT3 ? NT1 : NT3) : (NT2 > NT3 ? NT2 : NT3);
     const size_t lds_bytes = (size_t)2 * maxnt * 256 * sizeof(float);
     const unsigned grid = (unsigned)ceil_div(a.M, 64);
-    auto kern = k_fused_mlp<NT1, NT2, NT3, MINW>;
+    auto kern = k_fused_mlp<NT1, NT2, NT3, MINW, ACT_H, ACT_O>;
     if (lds_bytes > 64 * 1024) {
         HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
@@ -280,9 +396,29 @@ static int launch_mlp(const MlpArgs& a, hipStream_t s) {
     return HGNN_OK;
 }
 
+template <int NT1, int NT2, int NT3, int MINW>
+static int launch_mlp(const MlpArgs& a, hipStream_t s) {
+    const int n = NT3 == 0 ? 2 : 3;
+    bool hidden_gelu = true;
+    for (int l = 0; l + 1 < n; ++l) hidden_gelu = hidden_gelu && a.act[l] == HGNN_ACT_GELU;
+    const int out = a.act[n - 1];
+    if (hidden_gelu && out == HGNN_ACT_TANH) return launch_mlp_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_TANH>(a, s);
+    if (hidden_gelu && out == HGNN_ACT_GELU) return launch_mlp_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_GELU>(a, s);
+    return launch_mlp_act<NT1, NT2, NT3, MINW, -1, -1>(a, s);
+}
+
 }  // namespace hgnn
 
 using namespace hgnn;
+
+extern "C" int hgnn_mlp_set_stagger(int sleeps) {
+    if (sleeps <= -1000) {  // diagnostic ablation switch: -(1000 + bits)
+        g_opt_mlp_ablate = -sleeps - 1000;
+        return HGNN_OK;
+    }
+    g_opt_mlp_stagger = sleeps < 0 ? 0 : sleeps;
+    return HGNN_OK;
+}
 
 extern "C" int hgnn_mlp_supported(const hgnn_mlp_desc* d) {
     if (d == nullptr) return 0;
@@ -337,6 +473,9 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
                          "hgnn_mlp_forward_f32: layer %d parameters must be 16-byte aligned", l);
         }
     }
+    a.ablate = g_opt_mlp_ablate;
+    a.stagger = g_opt_mlp_stagger;
+    a.stagger_from = 256;
     a.eps = d->ln_eps;
     a.skip = d->skip;
     a.out = out;

@@ -195,6 +195,10 @@ typedef struct hgnn_mlp_desc {
  * K -> 2L (-> 2L) -> L with L in {32, 64, 128, 256}. */
 int hgnn_mlp_supported(const hgnn_mlp_desc* d);
 
+/* Tuning: one-time start delay, in units of s_sleep(127) (~3.4 us), applied to the second
+ * resident workgroup of every CU so that co-resident blocks do not run in lockstep. */
+int hgnn_mlp_set_stagger(int sleeps);
+
 /* out[M, L] = MLP(cat_i seg_i[idx_i]) (+ skip).  No workspace; hidden activations stay in
  * registers.  Negative gather indices read row 0 (callers validate indices at plan build). */
 int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_stream_t stream);
