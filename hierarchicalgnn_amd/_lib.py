@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
-CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID = 0, 1, 2, 3, 4
-ABI_VERSION = 4
+CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5
+ABI_VERSION = 5
 
 
 class HgnnPlan(Structure):

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void k_plan_rowptr(const int32_t* __restrict__
                                                      const int64_t* __restrict__ gather_index,
                                                      int64_t M, int64_t N,
                                                      int32_t* __restrict__ rowptr,
-                                                     int32_t* __restrict__ src_row) {
+                                                     int32_t* __restrict__ src_row,
+                                                     int32_t* __restrict__ counts) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p > M) return;
     int64_t prev = (p == 0) ? -1 : (int64_t)keys_sorted[p - 1];
@@ -61,6 +62,9 @@ __global__ __launch_bounds__(256) void k_plan_rowptr(const int32_t* __restrict__
     for (int64_t d = prev + 1; d <= cur; ++d) rowptr[d] = (int32_t)p;
     if (p < M) {
         int32_t e = perm[p];
+        // stable sort moved a row => the index was not sorted.  Plain store of a constant (benign
+        // race, every writer stores 1): an atomic here would serialise ~M updates on one address.
+        if (e != (int32_t)p) counts[HGNN_CNT_UNSORTED] = 1;
         int32_t r = e;
         if (gather_index != nullptr) r = (cur < N) ? (int32_t)gather_index[e] : 0;
         src_row[p] = r;
@@ -243,7 +247,7 @@ extern "C" int hgnn_plan_build(const int64_t* dst_index, const int64_t* gather_i
                                                  (size_t)M, 0u, (unsigned)key_bits(N), stream));
     }
     k_plan_rowptr<<<(unsigned)ceil_div(M + 1, 256), 256, 0, stream>>>(
-        keys_out, plan->perm, gather_index, M, N, plan->rowptr, plan->src_row);
+        keys_out, plan->perm, gather_index, M, N, plan->rowptr, plan->src_row, plan->counts);
     if (N > 0) {
         k_plan_chunks<<<(unsigned)ceil_div(N, 256), 256, 0, stream>>>(plan->rowptr, N, plan->chunk, tri_in);
         size_t tb = s.temp_bytes;

@@ -504,6 +504,8 @@ extern "C" int hgnn_segment_reduce_f32(const hgnn_plan* plan, const float* src, 
     if (plan->n_dst == 0) return HGNN_OK;
     HGNN_REQUIRE(out != nullptr, "hgnn_segment_reduce_f32: out is NULL");
     HGNN_REQUIRE(plan->n_rows == 0 || src != nullptr, "hgnn_segment_reduce_f32: src is NULL");
+    HGNN_REQUIRE(plan->src_row != nullptr || !plan->has_gather,
+                 "hgnn_segment_reduce_f32: src_row may only be NULL for a sorted plan without gather");
     HGNN_REQUIRE(partial != nullptr || plan->max_partial == 0, "hgnn_segment_reduce_f32: partial is NULL");
     HGNN_REQUIRE(((uintptr_t)src % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)partial % 16 == 0) || F % 4 != 0,
                  "hgnn_segment_reduce_f32: src/out/partial must be 16-byte aligned");

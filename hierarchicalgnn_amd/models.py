@@ -56,10 +56,23 @@ class InteractionGNNBlock(nn.Module):
     def forward(self, x, graph):
         if torch.is_grad_enabled() and x.is_leaf and not x.requires_grad:
             x.requires_grad = True                       # IN.py:82 (reentrant checkpoint needs a grad input)
+        # MI355X layout choice, invisible through the interface: run the whole block on the
+        # destination-sorted edge order.  The per-cell aggregation (gnn_utils.py:50) then reads
+        # each node's incoming edge rows as ONE contiguous HBM stream instead of gathering 1-KiB
+        # rows by edge id; the original order (which IN.py:126 relies on) is restored once at the end.
+        order = inverse = None
+        if self.hparams.get("sort_edges", True) and graph.is_cuda and graph.shape[1] > 0:
+            order = torch.argsort(graph[1], stable=True)
+            inverse = torch.empty_like(order)
+            inverse[order] = torch.arange(order.numel(), device=order.device)
+            graph = graph[:, order].contiguous()
         nodes = _maybe_checkpoint(self._ckpt, self._encode_nodes, x)              # IN.py:84
         edges = _maybe_checkpoint(self._ckpt, self._encode_edges, x, graph)       # IN.py:85
         for cell in self.ignn_cells:                                              # IN.py:87-88
             nodes, edges = cell(nodes, edges, graph)
+        if inverse is not None:
+            from .ops import gather_rows
+            edges = gather_rows(edges, inverse)
         if self.emb:
             emb = nn.functional.normalize(self.output_layer(nodes))
             return emb, nodes, edges

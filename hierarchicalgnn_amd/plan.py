@@ -93,11 +93,18 @@ class GraphPlan:
             # stream; the caching allocator orders their reuse after them.
         self.c = c
         self.validated = bool(validate)
+        self.sorted = False
         self._partial = {}
         _STATS["built"] += 1
         if validate:
             # one host sync per plan (= per event), never per aggregation call
-            if int(self.counts[_lib.CNT_ERR].item()) != 0:
+            host = self.counts.cpu()
+            # index already sorted by destination (a model-level layout choice, models.py): the
+            # reduce can stream rows begin..end contiguously instead of gathering them by id
+            if gather_index is None and int(host[_lib.CNT_UNSORTED]) == 0 and M > 0:
+                self.sorted = True
+                self.c.src_row = None
+            if int(host[_lib.CNT_ERR]) != 0:
                 raise RuntimeError(
                     f"GraphPlan: index out of range for dim_size={N}" +
                     (f" / source rows={R}" if gather_index is not None else ""))

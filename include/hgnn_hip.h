@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 4
+#define HGNN_ABI_VERSION 5
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -60,6 +60,7 @@ typedef void* hgnn_stream_t; /* hipStream_t */
 #define HGNN_CNT_PARTIAL 2  /* number of partial rows                       */
 #define HGNN_CNT_ERR 3      /* !=0: an index was out of range (row dropped) */
 #define HGNN_CNT_VALID 4    /* rows with a valid destination (and source)   */
+#define HGNN_CNT_UNSORTED 5 /* !=0: the index was not already sorted by destination */
 
 /*
  * A destination-sorted aggregation plan for one (index, dim_size) pair.  Built
@@ -78,7 +79,9 @@ typedef struct hgnn_plan {
     int64_t max_split;    /* capacity of split_dst; split_pbegin has +1           */
     int64_t max_partial;  /* rows of the partial-sum workspace                    */
     int32_t* perm;        /* [M]  original position of the p-th dst-sorted row (stable) */
-    int32_t* src_row;     /* [M]  source-table row read at sorted position p      */
+    int32_t* src_row;     /* [M]  source-table row read at sorted position p; the caller may set it
+                           *      to NULL when counts[HGNN_CNT_UNSORTED]==0 (index already sorted,
+                           *      no gather): the reduce then streams rows p = begin..end contiguously */
     int32_t* dst32;       /* [M]  destination of ORIGINAL position e, -1 if invalid */
     int32_t* rowptr;      /* [N+1] CSR by destination over sorted positions       */
     int32_t* wi_begin;    /* [max_work]                                           */

@@ -334,3 +334,24 @@ def test_c_abi_is_graph_capturable(H):
     ref = torch.zeros(N, F, device="cuda").index_add_(0, idx, src)
     assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) <= TOL
     assert torch.equal(back, gout[idx])
+
+
+def test_sorted_index_takes_the_streaming_path(H, O):
+    g = torch.Generator().manual_seed(13)
+    M, N, F = 30000, 500, 256
+    idx = torch.sort(torch.randint(0, N, (M,), generator=g)).values
+    idx[idx == 17] = 18                      # an empty destination inside the range
+    src = torch.randn(M, F, generator=g)
+    plan = H.get_plan(idx.cuda(), N)
+    assert plan.sorted and plan.c.src_row is None
+    out = H.scatter_add(src.cuda(), idx.cuda(), dim=0, dim_size=N, plan=plan)
+    assert rel_err(out.cpu().numpy(), O.scatter_add(src, idx, 0, N).numpy()) <= TOL
+    # backward through the sorted plan
+    s = src.cuda().requires_grad_(True)
+    r = torch.randn(N, F, generator=g).cuda()
+    (H.scatter_add(s, idx.cuda(), dim=0, dim_size=N) * r).sum().backward()
+    assert torch.equal(s.grad, r[idx.cuda()])
+    # an unsorted index does not
+    idx2 = idx.clone()
+    idx2[0], idx2[-1] = idx2[-1].item(), idx2[0].item()
+    assert not H.get_plan(idx2.cuda(), N).sorted
