@@ -64,7 +64,6 @@ _SIGNATURES = {
     "hgnn_index_to_i32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "hgnn_knn_radius_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p,
                                     c_void_p, c_void_p]),
-    "hgnn_mlp_set_stagger": (c_int, [c_int]),
     "hgnn_mlp_supported": (c_int, [POINTER(HgnnMlpDesc)]),
     "hgnn_mlp_forward_f32": (c_int, [POINTER(HgnnMlpDesc), c_void_p, c_void_p]),
 }

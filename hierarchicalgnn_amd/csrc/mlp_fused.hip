@@ -31,8 +31,8 @@ namespace hgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static int g_opt_mlp_stagger = 0;
-static int g_opt_mlp_ablate = 0;
+int g_opt_mlp_stagger = 0;  // set through hgnn_set_option("mlp_stagger", n)
+int g_opt_mlp_ablate = 0;   // set through hgnn_set_option("mlp_ablate", bits): DIAGNOSTIC, wrong results
 
 struct MlpArgs {
     const float* seg_table[3];
@@ -410,15 +410,6 @@ static int launch_mlp(const MlpArgs& a, hipStream_t s) {
 }  // namespace hgnn
 
 using namespace hgnn;
-
-extern "C" int hgnn_mlp_set_stagger(int sleeps) {
-    if (sleeps <= -1000) {  // diagnostic ablation switch: -(1000 + bits)
-        g_opt_mlp_ablate = -sleeps - 1000;
-        return HGNN_OK;
-    }
-    g_opt_mlp_stagger = sleeps < 0 ? 0 : sleeps;
-    return HGNN_OK;
-}
 
 extern "C" int hgnn_mlp_supported(const hgnn_mlp_desc* d) {
     if (d == nullptr) return 0;

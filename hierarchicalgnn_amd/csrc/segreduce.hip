@@ -23,6 +23,9 @@ namespace hgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+extern int g_opt_mlp_stagger;  // mlp_fused.hip
+extern int g_opt_mlp_ablate;
+
 static int g_opt_nt_loads = 1;   // non-temporal loads for once-read source rows
 static int g_opt_nt_stores = 0;  // non-temporal stores for gather output
 
@@ -488,6 +491,8 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     else if (!strcmp(name, "seg_unroll")) g_opt_seg_unroll = value;
     else if (!strcmp(name, "seg_wpb")) g_opt_seg_wpb = value;
     else if (!strcmp(name, "seg_xcd")) g_opt_seg_xcd = value;
+    else if (!strcmp(name, "mlp_stagger")) g_opt_mlp_stagger = value < 0 ? 0 : value;
+    else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 7;
     else {
         set_error("hgnn_set_option: unknown option '%s'", name);
         return HGNN_ERR_INVALID_ARG;

@@ -212,9 +212,14 @@ class HaloExchange:
             lists = [torch.empty(self.block, dtype=torch.long, device=self.device) for _ in range(shard.world)]
             dist.all_gather(lists, mine.to(self.device), group=group)
             flat = torch.cat([l.cpu() for l in lists])
-            lookup = {int(g): i for i, g in enumerate(flat.tolist()) if g >= 0}
-            self.halo_from_gathered = torch.tensor([lookup[int(g)] for g in shard.halo_global.tolist()],
-                                                   dtype=torch.long, device=self.device)
+            # position of every halo hit inside the gathered buffer (vectorised lookup)
+            valid = torch.nonzero(flat >= 0).squeeze(1)
+            keys, order = torch.sort(flat[valid])
+            pos = torch.searchsorted(keys, shard.halo_global)
+            assert bool((keys[pos.clamp(max=max(keys.numel() - 1, 0))] == shard.halo_global).all()) \
+                if shard.halo_global.numel() else True
+            self.halo_from_gathered = valid[order[pos]].to(self.device) if shard.halo_global.numel() \
+                else torch.zeros(0, dtype=torch.long, device=self.device)
         elif mode != "all_to_all":
             raise ValueError(mode)
 

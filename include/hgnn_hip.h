@@ -101,7 +101,11 @@ const char* hgnn_last_error(void);
 int hgnn_sizeof_plan(void);
 int hgnn_sizeof_mlp_desc(void);
 
-/* Tuning switches for A/B measurements ("nt_loads", "nt_stores", "seg_unroll", "seg_wpb", "seg_xcd"); process-wide. */
+/* Process-wide switches for A/B measurements:
+ *   "nt_loads", "nt_stores", "seg_unroll", "seg_wpb", "seg_xcd"   K1..K6 launch shape / cache policy
+ *   "mlp_stagger"  one-time start delay (x s_sleep 127) of every second resident wave slot
+ *   "mlp_ablate"   DIAGNOSTIC bits, results are WRONG: 1 skip LayerNorm/act, 2 skip weight DMA,
+ *                  4 skip barriers (used to price those parts; tools/tune_mlp.py) */
 int hgnn_set_option(const char* name, int value);
 
 /* Fills n_rows/n_dst/n_src/chunk/max_* of `plan` (pointers untouched).
@@ -197,10 +201,6 @@ typedef struct hgnn_mlp_desc {
  * every segment a multiple of 16 floats wide, LayerNorm on every layer, widths
  * K -> 2L (-> 2L) -> L with L in {32, 64, 128, 256}. */
 int hgnn_mlp_supported(const hgnn_mlp_desc* d);
-
-/* Tuning: one-time start delay, in units of s_sleep(127) (~3.4 us), applied to the second
- * resident workgroup of every CU so that co-resident blocks do not run in lockstep. */
-int hgnn_mlp_set_stagger(int sleeps);
 
 /* out[M, L] = MLP(cat_i seg_i[idx_i]) (+ skip).  No workspace; hidden activations stay in
  * registers.  Negative gather indices read row 0 (callers validate indices at plan build). */

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B the fused edge-MLP start stagger in one process (interleaved rounds)."""
+"""Price the parts of the fused edge MLP with its diagnostic ablation switches (one process,
+interleaved rounds).  Ablated variants compute WRONG results; only their time is meaningful."""
 import os
 import sys
 
@@ -18,18 +19,17 @@ edges = torch.randn(graph.shape[1], L, device="cuda")
 hp = dict(latent=L, hidden=2 * L, nb_edge_layer=2, nb_node_layer=3, layernorm=True, hidden_activation="GELU")
 cell = H.InteractionGNNCell(hp).cuda()
 flop = 2 * (3 * L * 2 * L + 2 * L * L) * graph.shape[1]
-variants = [0, -1001, -1002, -1003]  # 0 = real kernel; -(1000+bits): ablations (wrong results)
-times = {v: [] for v in variants}
+variants = [("real", 0), ("no LN/act", 1), ("no weight DMA", 2), ("no LN/act, no DMA", 3), ("no barriers", 4)]  # 0 = real kernel; -(1000+bits): ablations (wrong results)
+times = {v: [] for _, v in variants}
 ref = None
 with torch.no_grad():
     for rnd in range(4):
-        for v in variants:
-            lib.hgnn_mlp_set_stagger(-1000)  # clear any ablation bits
-            lib.hgnn_mlp_set_stagger(v)
+        for _, v in variants:
+            _lib.check(lib.hgnn_set_option(b"mlp_ablate", v))
             out = cell._edge_update(nodes, edges, graph)
             if ref is None:
                 ref = out.clone()
-            if v >= 0:
+            if v == 0:
                 assert torch.equal(out, ref)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -38,8 +38,7 @@ with torch.no_grad():
             e.record()
             torch.cuda.synchronize()
             times[v].append(s.elapsed_time(e) / 3)
-lib.hgnn_mlp_set_stagger(-1000)
-lib.hgnn_mlp_set_stagger(0)
-for v in variants:
+_lib.check(lib.hgnn_set_option(b"mlp_ablate", 0))
+for name, v in variants:
     t = sorted(times[v])
-    print(f"stagger {v:3d}: median {t[len(t)//2]:.3f} ms  min {t[0]:.3f} ms  {flop/t[len(t)//2]/1e9:.1f} TF/s")
+    print(f"{name:22s}: median {t[len(t)//2]:.3f} ms  min {t[0]:.3f} ms  {flop/t[len(t)//2]/1e9:.1f} TF/s")
