@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HgnnPlan(Structure):
@@ -59,6 +59,11 @@ _SIGNATURES = {
     "hgnn_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
     "hgnn_spread_rows_f32": (c_int, [POINTER(HgnnPlan), c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "hgnn_segment_reduce_bf16": (c_int, [POINTER(HgnnPlan), c_void_p, c_int32, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
+    "hgnn_spread_rows_bf16": (c_int, [POINTER(HgnnPlan), c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "hgnn_gather_rows_bf16": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_void_p]),
     "hgnn_edge_dot_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                   c_int64, c_void_p, c_void_p]),
     "hgnn_index_to_i32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

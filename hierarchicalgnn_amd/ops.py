@@ -22,41 +22,57 @@ from . import _lib
 from .plan import GraphPlan, get_plan
 
 
-def _require_hip(t: torch.Tensor, name: str):
+def _require_hip(t: torch.Tensor, name: str, allow_bf16: bool = False):
     if not t.is_cuda:
         raise RuntimeError(f"hierarchicalgnn_amd: `{name}` must be a HIP device tensor "
                            "(no CPU fallback; build + run on an MI355X)")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"hierarchicalgnn_amd: `{name}` must be float32, got {t.dtype}")
+    if t.dtype != torch.float32 and not (allow_bf16 and t.dtype == torch.bfloat16):
+        raise RuntimeError(f"hierarchicalgnn_amd: `{name}` must be float32"
+                           + (" or bfloat16" if allow_bf16 else "") + f", got {t.dtype}")
+
+
+def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """weights / row scales are always handed to the kernels as fp32"""
+    return None if t is None else (t if t.dtype == torch.float32 else t.float())
 
 
 def _seg_reduce(plan: GraphPlan, src2d: torch.Tensor, weight: Optional[torch.Tensor],
                 row_scale: Optional[torch.Tensor]) -> torch.Tensor:
     F = int(src2d.shape[1])
-    out = torch.empty((plan.N, F), dtype=torch.float32, device=src2d.device)
+    out = torch.empty((plan.N, F), dtype=src2d.dtype, device=src2d.device)
     if plan.N == 0 or F == 0:
         return out
     lib = _lib.load()
+    weight, row_scale = _f32(weight), _f32(row_scale)
+    bf16 = src2d.dtype == torch.bfloat16
+    fn = lib.hgnn_segment_reduce_bf16 if bf16 else lib.hgnn_segment_reduce_f32
     with torch.cuda.device(src2d.device):
-        _lib.check(lib.hgnn_segment_reduce_f32(
-            ctypes.byref(plan.c), _lib.ptr(src2d), F, _lib.ptr(weight), _lib.ptr(row_scale),
-            _lib.ptr(out), _lib.ptr(plan.partial(F)), _lib.current_stream(src2d.device)),
-            "hgnn_segment_reduce_f32")
+        _lib.check(fn(ctypes.byref(plan.c), _lib.ptr(src2d), F, _lib.ptr(weight), _lib.ptr(row_scale),
+                      _lib.ptr(out), _lib.ptr(plan.partial(F)), _lib.current_stream(src2d.device)),
+                   "hgnn_segment_reduce_bf16" if bf16 else "hgnn_segment_reduce_f32")
     return out
 
 
 def _gather_rows(table: torch.Tensor, idx32: torch.Tensor, M: int, weight: Optional[torch.Tensor] = None,
                  row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     F = int(table.shape[1])
-    out = torch.empty((M, F), dtype=torch.float32, device=table.device)
+    out = torch.empty((M, F), dtype=table.dtype, device=table.device)
     if M == 0 or F == 0:
         return out
     lib = _lib.load()
+    weight, row_scale = _f32(weight), _f32(row_scale)
     with torch.cuda.device(table.device):
-        _lib.check(lib.hgnn_gather_rows_f32(
-            _lib.ptr(table), int(table.shape[0]), F, _lib.ptr(idx32), M, _lib.ptr(weight),
-            _lib.ptr(row_scale), _lib.ptr(out), _lib.current_stream(table.device)),
-            "hgnn_gather_rows_f32")
+        if table.dtype == torch.bfloat16:
+            if row_scale is not None:
+                raise RuntimeError("gather_rows: row_scale is not implemented for bfloat16 tables")
+            _lib.check(lib.hgnn_gather_rows_bf16(
+                _lib.ptr(table), int(table.shape[0]), F, _lib.ptr(idx32), M, _lib.ptr(weight),
+                _lib.ptr(out), _lib.current_stream(table.device)), "hgnn_gather_rows_bf16")
+        else:
+            _lib.check(lib.hgnn_gather_rows_f32(
+                _lib.ptr(table), int(table.shape[0]), F, _lib.ptr(idx32), M, _lib.ptr(weight),
+                _lib.ptr(row_scale), _lib.ptr(out), _lib.current_stream(table.device)),
+                "hgnn_gather_rows_f32")
     return out
 
 
@@ -64,20 +80,24 @@ def _spread_rows(plan: GraphPlan, table: torch.Tensor, weight: Optional[torch.Te
     """out[e] = w[e] * table[index[e]] walked in destination order (each table row read once)"""
     F = int(table.shape[1])
     alloc = torch.empty if plan.validated else torch.zeros
-    out = alloc((plan.M, F), dtype=torch.float32, device=table.device)
+    out = alloc((plan.M, F), dtype=table.dtype, device=table.device)
     if plan.M == 0 or F == 0:
         return out
     lib = _lib.load()
+    weight = _f32(weight)
+    bf16 = table.dtype == torch.bfloat16
+    fn = lib.hgnn_spread_rows_bf16 if bf16 else lib.hgnn_spread_rows_f32
     with torch.cuda.device(table.device):
-        _lib.check(lib.hgnn_spread_rows_f32(ctypes.byref(plan.c), _lib.ptr(table), F, _lib.ptr(weight),
-                                            _lib.ptr(out), _lib.current_stream(table.device)),
-                   "hgnn_spread_rows_f32")
+        _lib.check(fn(ctypes.byref(plan.c), _lib.ptr(table), F, _lib.ptr(weight), _lib.ptr(out),
+                      _lib.current_stream(table.device)),
+                   "hgnn_spread_rows_bf16" if bf16 else "hgnn_spread_rows_f32")
     return out
 
 
 def _edge_dot(A: torch.Tensor, ai: Optional[torch.Tensor], B: torch.Tensor, bi: Optional[torch.Tensor],
               M: int) -> torch.Tensor:
     F = int(A.shape[1])
+    A, B = _f32(A), _f32(B)   # bf16 rows are widened once here (B <= 600k rows); the dot is fp32
     out = torch.empty((M,), dtype=torch.float32, device=A.device)
     if M == 0:
         return out
@@ -100,6 +120,7 @@ class _ScatterAdd(torch.autograd.Function):
         ctx.plan = plan
         ctx.has_w = weight is not None
         ctx.w_shape = weight.shape if weight is not None else None
+        ctx.w_dtype = weight.dtype if weight is not None else None
         if ctx.has_w:
             ctx.save_for_backward(src_c, w_c)
         return _seg_reduce(plan, src_c, w_c, None)
@@ -114,7 +135,7 @@ class _ScatterAdd(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 grad_src = _spread_rows(plan, g, weight=w_c)
             if ctx.needs_input_grad[1]:
-                grad_w = _edge_dot(src_c, None, g, plan.dst32, plan.M).view(ctx.w_shape)
+                grad_w = _edge_dot(src_c, None, g, plan.dst32, plan.M).view(ctx.w_shape).to(ctx.w_dtype)
         elif ctx.needs_input_grad[0]:
             grad_src = _spread_rows(plan, g)
         return grad_src, grad_w, None
@@ -134,7 +155,7 @@ def scatter_add(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size: 
         raise RuntimeError("hierarchicalgnn_amd.scatter_add: only dim=0 is implemented (the reference's use)")
     if out is not None:
         raise RuntimeError("hierarchicalgnn_amd.scatter_add: `out=` is not supported")
-    _require_hip(src, "src")
+    _require_hip(src, "src", allow_bf16=True)
     if index.dim() != 1 or index.shape[0] != src.shape[0]:
         raise RuntimeError("hierarchicalgnn_amd.scatter_add: index must be 1-D with one entry per row of src")
     if index.device != src.device:
@@ -152,7 +173,7 @@ def scatter_add(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size: 
         width *= int(t)
     src2d = src.reshape(src.shape[0], width)
     if weight is not None:
-        _require_hip(weight, "weight")
+        _require_hip(weight, "weight", allow_bf16=True)
         if weight.numel() != src.shape[0]:
             raise RuntimeError("hierarchicalgnn_amd.scatter_add: weight must have one entry per row")
     res = _ScatterAdd.apply(src2d, weight, plan)
@@ -169,8 +190,9 @@ class _GatherScaleScatter(torch.autograd.Function):
         w_c = weight.contiguous().view(-1)
         rs_c = row_scale.contiguous().view(-1) if row_scale is not None else None
         ctx.plan_fwd, ctx.plan_bwd = plan_fwd, plan_bwd
-        ctx.w_shape = weight.shape
+        ctx.w_shape, ctx.w_dtype = weight.shape, weight.dtype
         ctx.rs_shape = row_scale.shape if row_scale is not None else None
+        ctx.rs_dtype = row_scale.dtype if row_scale is not None else None
         ctx.save_for_backward(X_c, w_c, rs_c)
         return _seg_reduce(plan_fwd, X_c, w_c, rs_c)
 
@@ -185,9 +207,9 @@ class _GatherScaleScatter(torch.autograd.Function):
             T = _seg_reduce(pb, g, w_c, None)
             if rs_c is not None:
                 if ctx.needs_input_grad[2]:
-                    grad_rs = (T * X_c).sum(dim=1).view(ctx.rs_shape)
+                    grad_rs = (T.float() * X_c.float()).sum(dim=1).view(ctx.rs_shape).to(ctx.rs_dtype)
                 if ctx.needs_input_grad[0]:
-                    grad_X = T * rs_c.unsqueeze(1)
+                    grad_X = (T * rs_c.unsqueeze(1)).to(T.dtype)
             else:
                 grad_X = T
         if ctx.needs_input_grad[1]:
@@ -195,7 +217,7 @@ class _GatherScaleScatter(torch.autograd.Function):
             d = _edge_dot(g, pf.dst32, X_c, pb.dst32, pf.M)
             if rs_c is not None:
                 d = d * rs_c[pb.dst32.long()[:pf.M]] if pf.M else d
-            grad_w = d.view(ctx.w_shape)
+            grad_w = d.view(ctx.w_shape).to(ctx.w_dtype)
         return grad_X, grad_w, grad_rs, None, None
 
 
@@ -208,8 +230,8 @@ def gather_scale_scatter(X: torch.Tensor, gather_index: torch.Tensor, dst_index:
     K5: BipartiteClassification/Models/HGNN_GMM.py:269 (K3 with row_scale = 1/||nodes||_1)
     The [B, L] product is never written to HBM.  Differentiable w.r.t. X, weight, row_scale.
     """
-    _require_hip(X, "X")
-    _require_hip(weight, "weight")
+    _require_hip(X, "X", allow_bf16=True)
+    _require_hip(weight, "weight", allow_bf16=True)
     if X.dim() != 2:
         raise RuntimeError("gather_scale_scatter: X must be [rows, features]")
     if weight.numel() != gather_index.numel():
@@ -218,7 +240,7 @@ def gather_scale_scatter(X: torch.Tensor, gather_index: torch.Tensor, dst_index:
     plan_fwd = get_plan(dst_index, int(dim_size), gather_index, n_src)
     plan_bwd = get_plan(gather_index, n_src, dst_index, int(dim_size))
     if row_scale is not None:
-        _require_hip(row_scale, "row_scale")
+        _require_hip(row_scale, "row_scale", allow_bf16=True)
         if row_scale.numel() != n_src:
             raise RuntimeError("gather_scale_scatter: row_scale must have one entry per row of X")
     return _GatherScaleScatter.apply(X, weight, row_scale, plan_fwd, plan_bwd)
@@ -243,7 +265,7 @@ class _GatherRows(torch.autograd.Function):
 def gather_rows(table: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     """``table[index]`` for a 2-D table and a 1-D int64 index (Modules/gnn_utils.py:61,134,152).
     Forward is a whole-row HIP gather; backward is the atomics-free segmented reduce."""
-    _require_hip(table, "table")
+    _require_hip(table, "table", allow_bf16=True)
     if table.dim() != 2 or index.dim() != 1:
         raise RuntimeError("gather_rows: table must be 2-D and index 1-D")
     plan = get_plan(index, int(table.shape[0]))

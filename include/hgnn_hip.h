@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 5
+#define HGNN_ABI_VERSION 6
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -146,6 +146,16 @@ int hgnn_gather_rows_f32(const float* table, int64_t table_rows, int32_t F,
  * are not written. */
 int hgnn_spread_rows_f32(const hgnn_plan* plan, const float* table, int32_t F,
                          const float* weight, float* out, hgnn_stream_t stream);
+
+/* bf16 feature rows (BASELINE config 4 dtype): same semantics as the _f32 entry points with
+ * bf16 src/table/out (16-byte aligned, F a multiple of 8, F <= 512), fp32 accumulation and one
+ * rounding per output element; weight / row_scale stay fp32; `partial` is fp32[max_partial,F]. */
+int hgnn_segment_reduce_bf16(const hgnn_plan* plan, const void* src, int32_t F, const float* weight,
+                             const float* row_scale, void* out, float* partial, hgnn_stream_t stream);
+int hgnn_spread_rows_bf16(const hgnn_plan* plan, const void* table, int32_t F, const float* weight,
+                          void* out, hgnn_stream_t stream);
+int hgnn_gather_rows_bf16(const void* table, int64_t table_rows, int32_t F, const int32_t* idx, int64_t M,
+                          const float* weight, void* out, hgnn_stream_t stream);
 
 /* out[e] = sum_f A[ai[e],f] * B[bi[e],f];  ai/bi int32[M] or NULL (identity);
  * negative index -> 0. */

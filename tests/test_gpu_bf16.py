@@ -1,0 +1,72 @@
+"""bf16 feature rows (BASELINE config 4 dtype) through hgnn_*_bf16: fp32 accumulation, one rounding.
+Oracle: the fp32 CPU restatement applied to the bf16-rounded inputs, rounded to bf16 once."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+BF16_TOL = 2.0 ** -7   # one bf16 ulp at the scale of the largest element (8 significant bits)
+
+
+@pytest.mark.parametrize("F", [32, 64, 128, 256, 512, 40])
+def test_k1_bf16_forward_backward(F):
+    import hierarchicalgnn_amd as H
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(F)
+    M, N = 4000, 211
+    src = torch.randn(M, F, generator=g).bfloat16()
+    idx = torch.randint(0, N, (M,), generator=g)
+    idx[:900] = 5                                    # list splitting
+    ref = O.scatter_add(src.float(), idx, 0, N)      # fp32 accumulation of the bf16 values
+    s = src.cuda().requires_grad_(True)
+    out = H.scatter_add(s, idx.cuda(), dim=0, dim_size=N)
+    assert out.dtype == torch.bfloat16
+    o = out.detach().float().cpu()
+    assert rel_err(o.numpy(), ref.numpy()) <= BF16_TOL
+    # one rounding only: almost every element equals the correctly rounded fp32 sum
+    assert float((o == ref.bfloat16().float()).float().mean()) > 0.98
+    r = torch.randn(N, F, generator=g).bfloat16().cuda()
+    (out * r).sum().backward()
+    assert s.grad.dtype == torch.bfloat16
+    assert torch.equal(s.grad, r[idx.cuda()])
+
+
+def test_weighted_and_gathered_bf16():
+    import hierarchicalgnn_amd as H
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(3)
+    N, S, B, F = 500, 31, 2600, 512
+    X = torch.randn(N, F, generator=g).bfloat16()
+    gi = torch.randint(0, N, (B,), generator=g)
+    di = torch.randint(0, S, (B,), generator=g)
+    w = torch.exp(0.3 * torch.randn(B, 1, generator=g))
+    ref = O.scatter_add(w * X.float()[gi], di, 0, S)
+    Xd = X.cuda().requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    out = H.gather_scale_scatter(Xd, gi.cuda(), di.cuda(), S, wd)
+    assert out.dtype == torch.bfloat16
+    assert rel_err(out.detach().float().cpu().numpy(), ref.numpy()) <= BF16_TOL
+    r = torch.randn(S, F, generator=g).bfloat16()
+    (out * r.cuda()).sum().backward()
+    Xr = X.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    (O.scatter_add(wr * Xr[gi], di, 0, S) * r.float()).sum().backward()
+    assert Xd.grad.dtype == torch.bfloat16 and wd.grad.dtype == torch.float32
+    assert rel_err(Xd.grad.float().cpu().numpy(), Xr.grad.numpy()) <= 2 * BF16_TOL
+    assert rel_err(wd.grad.cpu().numpy(), wr.grad.numpy()) <= 2 * BF16_TOL
+
+
+def test_gather_rows_bf16_exact():
+    import hierarchicalgnn_amd as H
+    g = torch.Generator().manual_seed(4)
+    t = torch.randn(300, 256, generator=g).bfloat16()
+    idx = torch.randint(0, 300, (5000,), generator=g)
+    out = H.gather_rows(t.cuda(), idx.cuda())
+    assert torch.equal(out.cpu(), t[idx])
+
+
+def test_bf16_unsupported_width_is_an_error():
+    import hierarchicalgnn_amd as H
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        H.scatter_add(torch.zeros(10, 12).bfloat16().cuda(), torch.zeros(10, dtype=torch.long).cuda(), dim_size=2)

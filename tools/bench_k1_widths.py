@@ -32,4 +32,21 @@ for L in (32, 64, 128, 256, 512):
     out[f"L{L}"] = {"ms": t, "alg_bytes": b, "GBps": b / t / 1e6, "frac_of_8TBps": b / t / 1e6 / 8000,
                     "edges_per_s": M / t * 1e3}
     del src
+# BASELINE config 4 dtype: latent=512 bf16 (a 1-KiB row again)
+src = torch.randn(M, 512, device="cuda").bfloat16()
+for _ in range(3):
+    H.scatter_add(src, graph[1], dim_size=N, plan=plan)
+ts = []
+for _ in range(20):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    H.scatter_add(src, graph[1], dim_size=N, plan=plan)
+    e.record()
+    torch.cuda.synchronize()
+    ts.append(s.elapsed_time(e))
+ts.sort()
+t = ts[len(ts) // 2]
+b = 2 * 512 * M + 4 * M + 2 * 512 * N
+out["L512_bf16"] = {"ms": t, "alg_bytes": b, "GBps": b / t / 1e6, "frac_of_8TBps": b / t / 1e6 / 8000,
+                    "edges_per_s": M / t * 1e3}
 print(json.dumps(out, indent=1))
