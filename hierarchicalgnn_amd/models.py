@@ -53,28 +53,40 @@ class InteractionGNNBlock(nn.Module):
     def _encode_edges(self, x, graph):
         return concat_mlp(self.edge_encoder, [(x, graph[0]), (x, graph[1])])
 
-    def forward(self, x, graph):
+    def run(self, x, graph, restore_order=True):
+        """The block on the destination-sorted layout.  Returns (emb or None, nodes, edges, graph_used,
+        order): with ``restore_order`` the edges/graph come back in the caller's order (order=None);
+        without it they stay destination-sorted and ``order`` maps sorted position -> original column
+        (a caller that only needs node-level outputs, like the BC model, never pays the un-permute)."""
         if torch.is_grad_enabled() and x.is_leaf and not x.requires_grad:
             x.requires_grad = True                       # IN.py:82 (reentrant checkpoint needs a grad input)
         # MI355X layout choice, invisible through the interface: run the whole block on the
         # destination-sorted edge order.  The per-cell aggregation (gnn_utils.py:50) then reads
         # each node's incoming edge rows as ONE contiguous HBM stream instead of gathering 1-KiB
         # rows by edge id; the original order (which IN.py:126 relies on) is restored once at the end.
-        order = inverse = None
+        order = None
+        graph_in = graph
         if self.hparams.get("sort_edges", True) and graph.is_cuda and graph.shape[1] > 0:
             order = torch.argsort(graph[1], stable=True)
-            inverse = torch.empty_like(order)
-            inverse[order] = torch.arange(order.numel(), device=order.device)
             graph = graph[:, order].contiguous()
         nodes = _maybe_checkpoint(self._ckpt, self._encode_nodes, x)              # IN.py:84
         edges = _maybe_checkpoint(self._ckpt, self._encode_edges, x, graph)       # IN.py:85
         for cell in self.ignn_cells:                                              # IN.py:87-88
             nodes, edges = cell(nodes, edges, graph)
-        if inverse is not None:
+        if order is not None and restore_order:
             from .ops import gather_rows
+            inverse = torch.empty_like(order)
+            inverse[order] = torch.arange(order.numel(), device=order.device)
             edges = gather_rows(edges, inverse)
+            graph, order = graph_in, None
+        emb = None
         if self.emb:
             emb = nn.functional.normalize(self.output_layer(nodes))
+        return emb, nodes, edges, graph, order
+
+    def forward(self, x, graph):
+        emb, nodes, edges, _, _ = self.run(x, graph, restore_order=True)
+        if self.emb:
             return emb, nodes, edges
         return nodes, edges
 
@@ -191,11 +203,15 @@ class BC_MessagePassing(nn.Module):
                                                output_activation=None,
                                                hidden_activation=hparams["hidden_output_activation"])
 
-    def embed(self, x, graph):
-        """HGNN_GMM.py:328-331: returns (directed_graph, embeddings[N,emb_dim], nodes, edges)"""
+    def embed(self, x, graph, restore_order=False):
+        """HGNN_GMM.py:328-331: returns (directed_graph, embeddings[N,emb_dim], nodes, edges, order).
+        By default the directed graph and the edge latents stay in the destination-sorted layout
+        (``order`` = sorted position -> column of cat([graph, graph.flip(0)])): the BC model only
+        returns node-level quantities, so the HGNN block keeps streaming on that layout and the
+        un-permute is never paid."""
         directed_graph = torch.cat([graph, graph.flip(0)], dim=1)
-        emb, nodes, edges = self.ignn_block(x, directed_graph)
-        return directed_graph, emb, nodes, edges
+        emb, nodes, edges, directed_graph, order = self.ignn_block.run(x, directed_graph, restore_order)
+        return directed_graph, emb, nodes, edges, order
 
     def score(self, nodes, supernodes, bipartite_graph):
         """HGNN_GMM.py:342-344"""

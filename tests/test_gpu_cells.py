@@ -133,10 +133,13 @@ def test_bc_hgnn_message_passing_against_reference_forward():
     graph = torch.from_numpy(z["edge_index"]).cuda()
     t = lambda k: torch.from_numpy(z[k]).cuda()
     with torch.no_grad():
-        directed, emb, nodes, edges = model.embed(x, graph)
+        directed, emb, nodes, edges, order = model.embed(x, graph)
+        assert order is not None and bool((directed[1][1:] >= directed[1][:-1]).all())   # sorted layout
         assert rel_err(emb.cpu().numpy(), z["embeddings"]) <= TOL
         assert rel_err(nodes.cpu().numpy(), z["cell0.in.nodes"]) <= TOL
-        assert rel_err(edges.cpu().numpy(), z["cell0.in.edges"]) <= TOL
+        assert rel_err(edges.cpu().numpy(), z["cell0.in.edges"][order.cpu().numpy()]) <= TOL
+        d2, _, _, e2, o2 = model.embed(x, graph, restore_order=True)                     # interface order
+        assert o2 is None and rel_err(e2.cpu().numpy(), z["cell0.in.edges"]) <= TOL
         means = t("cell0.in.supernodes")[:, :hp["emb_dim"]].contiguous()
         bg, bw = t("cell0.in.bipartite_graph"), t("cell0.in.bipartite_edge_weights")
         sg, sw = t("cell0.in.super_graph"), t("cell0.in.super_edge_weights")
