@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HgnnPlan(Structure):
@@ -42,6 +42,8 @@ class HgnnMlpDesc(Structure):
         ("ln_eps", c_float),
         ("skip", c_void_p),
         ("M", c_int64),
+        ("w0_cols", c_int32),
+        ("w_last_rows", c_int32),
     ]
 
 

@@ -39,7 +39,9 @@ struct MlpArgs {
     const int32_t* seg_index[3];
     int seg_width[3];
     int n_seg;
-    int K1;
+    int K1;       // columns stored in W[0] (multiple of 16)
+    int K1_real;  // concatenated input width; < K1 only in small-K mode (K1_real <= 16, W[0] zero padded)
+    int out_real; // 1: the last layer is plain (no LayerNorm/act) with ONE real output (heads); else 0
     const float* W[3];
     const float* b[3];
     const float* lnw[3];
@@ -154,9 +156,10 @@ __device__ __forceinline__ void stage_w(const float* __restrict__ W, int Kdim, i
 }
 
 // acc[T][r] (edge = lane&15, feature = 16T + 4*(lane>>4) + r): LayerNorm over features, then act
-template <int NT, int ACT>
+template <int NT, int ACT, bool LN = true>
 __device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT], const float* __restrict__ lnw,
                                               const float* __restrict__ lnb, int act, float eps, int g) {
+    if (!LN) return;  // plain last layer of a head: bias only
     constexpr float inv_n = 1.0f / (float)(NT * 16);
     float s = 0.f;
 #pragma unroll
@@ -262,6 +265,10 @@ template <int NT>
 __device__ __forceinline__ void store_out(const f32x4 (&acc)[NT], const MlpArgs& a, long long e, bool valid,
                                           int g) {
     if (!valid) return;
+    if (a.out_real == 1) {  // head: feature 0 of tile 0 (lanes g == 0, register x); the rest is padding
+        if (g == 0) a.out[e] = acc[0].x;
+        return;
+    }
     constexpr int NOUT = NT * 16;
     float* op = a.out + (size_t)e * NOUT + g * 4;
     if (a.skip != nullptr) {
@@ -277,7 +284,8 @@ __device__ __forceinline__ void store_out(const f32x4 (&acc)[NT], const MlpArgs&
 // NT1/NT2/NT3: 16-feature tiles of layer 1 / 2 / 3 outputs (NT3 == 0: two-layer MLP)
 // ACT_H / ACT_O: activation of the hidden layers / of the last layer (HGNN_ACT_*), or -1 = read
 // it from the descriptor per element (keeps rare combinations working without an instantiation)
-template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O>
+// PLAIN_LAST: the last layer has no LayerNorm / activation (classifier heads, width-1 output)
+template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, bool PLAIN_LAST = false>
 __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -323,9 +331,29 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     const int c2 = c1 + (a.n_seg > 1 ? a.seg_width[1] / 16 : nc);  // first chunk of segment 2
     const float* px = q0;
     int cl = 0;  // next chunk the X stream will load
+    // small-K mode (encoders: K = 3 or 6 spatial coordinates): one zero-padded chunk, assembled
+    // from scalar loads because a 12-byte row is not 16-byte addressable
+    const bool smallk = a.K1_real < a.K1;  // wave-uniform
+    auto small_x = [&]() -> f32x4 {
+        const float* r0 = q0 - g * 4;
+        const float* r1 = q1 - g * 4;
+        const float* r2 = q2 - g * 4;
+        const int w0 = a.seg_width[0], w1 = a.n_seg > 1 ? a.seg_width[1] : 0, w2 = a.n_seg > 2 ? a.seg_width[2] : 0;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = g * 4 + r;
+            float t = 0.f;
+            if (k < w0) t = r0[k];
+            else if (k < w0 + w1) t = r1[k - w0];
+            else if (k < w0 + w1 + w2) t = r2[k - w0 - w1];
+            v[r] = t;
+        }
+        return v;
+    };
     auto next_x = [&](f32x4 fallback) -> f32x4 {
         f32x4 v = fallback;
-        if (cl < nc) v = *(const f32x4*)px;
+        if (cl < nc && !smallk) v = *(const f32x4*)px;
         ++cl;
         px += 16;
         if (cl == c1) px = q1;
@@ -342,7 +370,7 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         stage_w<NT1 * 16>(a.W[0], a.K1, 0, lds, wave, lane);
         const int n_pieces = pieces_of<NT1 * 16>(wave);
-        f32x4 x0 = next_x(zero);
+        f32x4 x0 = smallk ? small_x() : next_x(zero);
         f32x4 x1 = next_x(zero);
         for (int c = 0; c < nc; ++c) {
             wait_dma();
@@ -367,7 +395,9 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     init_bias<NT2>(acc2, a.b[1], g);
     dense_from_regs<NT1, NT2>(acc1, acc2, a.W[1], lds, wave, lane, a.ablate);
     __builtin_amdgcn_s_setprio(0);
-    if (!(a.ablate & 1)) layernorm_act<NT2, (NT3 == 0 ? ACT_O : ACT_H)>(acc2, a.lnw[1], a.lnb[1], a.act[1], a.eps, g);
+    if (!(a.ablate & 1))
+        layernorm_act<NT2, (NT3 == 0 ? ACT_O : ACT_H), !(PLAIN_LAST && NT3 == 0)>(acc2, a.lnw[1], a.lnb[1], a.act[1],
+                                                                                  a.eps, g);
     if constexpr (NT3 == 0) {
         store_out<NT2>(acc2, a, e, valid, g);
     } else {
@@ -376,17 +406,17 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
         __builtin_amdgcn_s_setprio(2);
         dense_from_regs<NT2, NT3>(acc2, acc3, a.W[2], lds, wave, lane, a.ablate);
         __builtin_amdgcn_s_setprio(0);
-        if (!(a.ablate & 1)) layernorm_act<NT3, ACT_O>(acc3, a.lnw[2], a.lnb[2], a.act[2], a.eps, g);
+        if (!(a.ablate & 1)) layernorm_act<NT3, ACT_O, !PLAIN_LAST>(acc3, a.lnw[2], a.lnb[2], a.act[2], a.eps, g);
         store_out<NT3>(acc3, a, e, valid, g);
     }
 }
 
-template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O>
+template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, bool PLAIN_LAST = false>
 static int launch_mlp_act(const MlpArgs& a, hipStream_t s) {
     constexpr int maxnt = NT1 > NT2 ? (NT1 > NT3 ? NT1 : NT3) : (NT2 > NT3 ? NT2 : NT3);
     const size_t lds_bytes = (size_t)2 * maxnt * 256 * sizeof(float);
     const unsigned grid = (unsigned)ceil_div(a.M, 64);
-    auto kern = k_fused_mlp<NT1, NT2, NT3, MINW, ACT_H, ACT_O>;
+    auto kern = k_fused_mlp<NT1, NT2, NT3, MINW, ACT_H, ACT_O, PLAIN_LAST>;
     if (lds_bytes > 64 * 1024) {
         HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
@@ -407,6 +437,18 @@ static int launch_mlp(const MlpArgs& a, hipStream_t s) {
     return launch_mlp_act<NT1, NT2, NT3, MINW, -1, -1>(a, s);
 }
 
+// classifier heads: K -> H -> H -> 1 (padded to 32 rows), LayerNorm + act on the two hidden layers only
+template <int NTH, int MINW>
+static int launch_head(const MlpArgs& a, hipStream_t s) {
+    if (a.act[0] == HGNN_ACT_GELU && a.act[1] == HGNN_ACT_GELU)
+        return launch_mlp_act<NTH, NTH, 2, MINW, HGNN_ACT_GELU, HGNN_ACT_NONE, true>(a, s);
+    if (a.act[0] == HGNN_ACT_TANH && a.act[1] == HGNN_ACT_TANH)
+        return launch_mlp_act<NTH, NTH, 2, MINW, HGNN_ACT_TANH, HGNN_ACT_NONE, true>(a, s);
+    return launch_mlp_act<NTH, NTH, 2, MINW, -1, HGNN_ACT_NONE, true>(a, s);
+}
+
+static bool is_head(const hgnn_mlp_desc* d) { return d->width[d->n_layers] == 1; }
+
 }  // namespace hgnn
 
 using namespace hgnn;
@@ -415,16 +457,34 @@ extern "C" int hgnn_mlp_supported(const hgnn_mlp_desc* d) {
     if (d == nullptr) return 0;
     if (d->n_seg < 1 || d->n_seg > 3 || (d->n_layers != 2 && d->n_layers != 3)) return 0;
     int k = 0;
+    bool aligned16 = true;
     for (int s = 0; s < d->n_seg; ++s) {
-        if (d->seg_width[s] <= 0 || d->seg_width[s] % 16 != 0) return 0;
+        if (d->seg_width[s] <= 0) return 0;
+        aligned16 = aligned16 && d->seg_width[s] % 16 == 0;
         k += d->seg_width[s];
     }
     if (k != d->width[0]) return 0;
-    for (int l = 0; l < d->n_layers; ++l)
-        if (d->ln_w[l] == nullptr || d->ln_b[l] == nullptr || d->W[l] == nullptr || d->b[l] == nullptr) return 0;
+    if (!aligned16) {  // small-K mode: one zero-padded 16-column chunk
+        if (k > 16 || d->w0_cols != 16) return 0;
+    } else if (d->w0_cols != 0 && d->w0_cols != k) {
+        return 0;
+    }
+    const int n = d->n_layers;
+    for (int l = 0; l < n; ++l)
+        if (d->W[l] == nullptr || d->b[l] == nullptr) return 0;
     const int h = d->width[1];
-    const int o = d->width[d->n_layers];
-    if (d->n_layers == 3 && d->width[2] != h) return 0;
+    const int o = d->width[n];
+    if (n == 3 && d->width[2] != h) return 0;
+    if (is_head(d)) {
+        // K -> H -> H -> 1: LayerNorm on the hidden layers only, plain last layer stored as 32 rows
+        if (n != 3 || d->w_last_rows != 32 || d->ln_w[2] != nullptr || d->act[2] != HGNN_ACT_NONE) return 0;
+        if (d->ln_w[0] == nullptr || d->ln_b[0] == nullptr || d->ln_w[1] == nullptr || d->ln_b[1] == nullptr) return 0;
+        if (d->skip != nullptr) return 0;
+        return (h == 64 || h == 128 || h == 256 || h == 512) ? 1 : 0;
+    }
+    for (int l = 0; l < n; ++l)
+        if (d->ln_w[l] == nullptr || d->ln_b[l] == nullptr) return 0;
+    if (d->w_last_rows != 0 && d->w_last_rows != o) return 0;
     if (h != 2 * o) return 0;
     return (o == 32 || o == 64 || o == 128 || o == 256) ? 1 : 0;
 }
@@ -433,8 +493,9 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
     hipStream_t stream = (hipStream_t)stream_;
     HGNN_REQUIRE(d != nullptr && out != nullptr, "hgnn_mlp_forward_f32: NULL argument");
     if (!hgnn_mlp_supported(d)) {
-        set_error("hgnn_mlp_forward_f32: unsupported shape (segments must be multiples of 16 wide, "
-                  "LayerNorm on every layer, widths K -> 2L (-> 2L) -> L with L in {32,64,128,256})");
+        set_error("hgnn_mlp_forward_f32: unsupported shape (see hgnn_mlp_supported in include/hgnn_hip.h: "
+                  "K -> 2L (-> 2L) -> L with LayerNorm everywhere, L in {32,64,128,256}, segments multiples "
+                  "of 16 or K <= 16 zero-padded; or a K -> H -> H -> 1 head)");
         return HGNN_ERR_UNSUPPORTED;
     }
     if (d->M == 0) return HGNN_OK;
@@ -450,7 +511,9 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
         }
     }
     a.n_seg = d->n_seg;
-    a.K1 = d->width[0];
+    a.K1_real = d->width[0];
+    a.K1 = d->w0_cols != 0 ? d->w0_cols : d->width[0];
+    a.out_real = is_head(d) ? 1 : 0;
     for (int l = 0; l < 3; ++l) {
         const bool on = l < d->n_layers;
         a.W[l] = on ? d->W[l] : nullptr;
@@ -463,6 +526,7 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
                              (uintptr_t)a.lnw[l] % 16 == 0 && (uintptr_t)a.lnb[l] % 16 == 0,
                          "hgnn_mlp_forward_f32: layer %d parameters must be 16-byte aligned", l);
         }
+        if (on && a.lnw[l] == nullptr) a.lnw[l] = a.lnb[l] = a.b[l];  // never dereferenced (plain layer)
     }
     a.ablate = g_opt_mlp_ablate;
     a.stagger = g_opt_mlp_stagger;
@@ -473,6 +537,14 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
     a.M = d->M;
     HGNN_REQUIRE((uintptr_t)out % 16 == 0 && (uintptr_t)a.skip % 16 == 0,
                  "hgnn_mlp_forward_f32: out/skip must be 16-byte aligned");
+    if (is_head(d)) {
+        switch (d->width[1]) {
+            case 64: return launch_head<4, 2>(a, stream);
+            case 128: return launch_head<8, 2>(a, stream);
+            case 256: return launch_head<16, 2>(a, stream);
+            case 512: return launch_head<32, 1>(a, stream);
+        }
+    }
     const int o = d->width[d->n_layers];
     if (d->n_layers == 2) {
         switch (o) {

@@ -31,26 +31,37 @@ def set_enabled(flag: bool):
 
 
 def _parse(net: nn.Sequential):
-    """[(Linear, LayerNorm, act_code)] or None if the Sequential is not Linear->LN->act repeated"""
+    """[(Linear, LayerNorm or None, act_code)] or None if the Sequential is not
+    (Linear -> LayerNorm -> act) repeated, optionally ending in one plain Linear (a head)"""
     mods = list(net)
-    if len(mods) % 3 != 0 or not mods:
-        return None
     layers = []
-    for i in range(0, len(mods), 3):
-        lin, ln, act = mods[i], mods[i + 1], mods[i + 2]
-        if not isinstance(lin, nn.Linear) or not isinstance(ln, nn.LayerNorm) or type(act) not in _ACT:
+    i = 0
+    while i < len(mods):
+        lin = mods[i]
+        if not isinstance(lin, nn.Linear) or lin.bias is None:
+            return None
+        if i + 1 == len(mods):                       # plain last layer (output_activation=None)
+            layers.append((lin, None, 0))
+            break
+        if i + 2 >= len(mods):
+            return None
+        ln, act = mods[i + 1], mods[i + 2]
+        if not isinstance(ln, nn.LayerNorm) or type(act) not in _ACT:
             return None
         if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") != "none":
             return None
-        if lin.bias is None or not ln.elementwise_affine or ln.bias is None:
+        if not ln.elementwise_affine or ln.bias is None:
             return None
         layers.append((lin, ln, _ACT[type(act)]))
-    return layers
+        i += 3
+    return layers or None
 
 
 def _descriptor(net, segments, skip):
     layers = _parse(net)
     if layers is None or len(layers) not in (2, 3) or not (1 <= len(segments) <= 3):
+        return None
+    if any(ln is None for _, ln, _ in layers[:-1]):
         return None
     d = _lib.HgnnMlpDesc()
     keep = []
@@ -74,26 +85,52 @@ def _descriptor(net, segments, skip):
             d.seg_index[i] = i32.data_ptr() if i32.numel() else None
         else:
             d.seg_index[i] = None
-    d.n_layers = len(layers)
-    d.width[0] = sum(int(t.shape[1]) for t, _ in segments)
+    n = len(layers)
+    d.n_layers = n
+    K = sum(int(t.shape[1]) for t, _ in segments)
+    d.width[0] = K
     eps = None
     for l, (lin, ln, act) in enumerate(layers):
         if lin.in_features != d.width[l]:
             return None
-        for p in (lin.weight, lin.bias, ln.weight, ln.bias):
+        params = [lin.weight, lin.bias] + ([ln.weight, ln.bias] if ln is not None else [])
+        for p in params:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                 return None
-        d.W[l], d.b[l] = lin.weight.data_ptr(), lin.bias.data_ptr()
-        d.ln_w[l], d.ln_b[l] = ln.weight.data_ptr(), ln.bias.data_ptr()
+        W, b = lin.weight, lin.bias
+        if l == 0 and any(int(t.shape[1]) % 16 for t, _ in segments):
+            if K > 16:
+                return None
+            # small-K mode (encoders, K = 3 / 6): one zero-padded 16-column chunk
+            W = torch.nn.functional.pad(W.detach(), (0, 16 - K)).contiguous()
+            keep.append(W)
+            d.w0_cols = 16
+        if l == n - 1 and ln is None:
+            if lin.out_features != 1:
+                return None
+            # width-1 head: the plain last layer is stored zero-padded as 32 rows
+            Wp = torch.zeros((32, lin.in_features), dtype=torch.float32, device=W.device)
+            Wp[0] = W.detach()[0]
+            bp = torch.zeros(32, dtype=torch.float32, device=W.device)
+            bp[0] = b.detach()[0]
+            keep += [Wp, bp]
+            W, b = Wp, bp
+            d.w_last_rows = 32
+        d.W[l], d.b[l] = W.data_ptr(), b.data_ptr()
+        if ln is not None:
+            d.ln_w[l], d.ln_b[l] = ln.weight.data_ptr(), ln.bias.data_ptr()
+            if eps is None:
+                eps = ln.eps
+            elif eps != ln.eps:
+                return None
+        else:
+            d.ln_w[l] = d.ln_b[l] = None
         d.width[l + 1] = lin.out_features
         d.act[l] = act
-        if eps is None:
-            eps = ln.eps
-        elif eps != ln.eps:
-            return None
     d.ln_eps = float(eps)
+    n_out = int(d.width[n])
     if skip is not None:
-        if tuple(skip.shape) != (M, d.width[len(layers)]) or not skip.is_cuda or skip.dtype != torch.float32:
+        if tuple(skip.shape) != (M, n_out) or not skip.is_cuda or skip.dtype != torch.float32:
             return None
         sk = skip if skip.is_contiguous() else skip.contiguous()
         keep.append(sk)
@@ -101,7 +138,7 @@ def _descriptor(net, segments, skip):
     else:
         d.skip = None
     d.M = M
-    return d, keep, M, int(d.width[len(layers)])
+    return d, keep, M, n_out
 
 
 def supported(net, segments, skip) -> bool:

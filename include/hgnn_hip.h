@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 6
+#define HGNN_ABI_VERSION 7
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -205,11 +205,20 @@ typedef struct hgnn_mlp_desc {
     float ln_eps;
     const float* skip;           /* [M, out] added to the result, or NULL         */
     int64_t M;                   /* rows                                          */
+    int32_t w0_cols;             /* columns stored per row of W[0]: 0 = width[0]; must be 16 (zero
+                                  * padded) in small-K mode, i.e. when width[0] <= 16 is not a
+                                  * multiple of 16 (node / edge encoders, K = 3 / 6: IN.py:26-46)  */
+    int32_t w_last_rows;         /* rows stored in the last W / b: 0 = width[n]; must be 32 (zero
+                                  * padded) for a width-1 head (IN.py:107-115, HGNN_GMM.py:313-321) */
 } hgnn_mlp_desc;
 
 /* 1 if hgnn_mlp_forward_f32 has an instantiation for this descriptor (host-only check):
- * every segment a multiple of 16 floats wide, LayerNorm on every layer, widths
- * K -> 2L (-> 2L) -> L with L in {32, 64, 128, 256}. */
+ *   cell networks / encoders: widths K -> 2L (-> 2L) -> L, LayerNorm on every layer,
+ *       L in {32, 64, 128, 256}; every segment a multiple of 16 floats wide, or K <= 16 in
+ *       small-K mode (W[0] zero-padded to 16 columns, w0_cols = 16);
+ *   heads: K -> H -> H -> 1, LayerNorm + activation on the two hidden layers, plain last layer
+ *       (ln_w[2] = NULL, act[2] = NONE) stored zero-padded as 32 rows (w_last_rows = 32),
+ *       H in {64, 128, 256, 512}, no skip; out is float[M]. */
 int hgnn_mlp_supported(const hgnn_mlp_desc* d);
 
 /* out[M, L] = MLP(cat_i seg_i[idx_i]) (+ skip).  No workspace; hidden activations stay in

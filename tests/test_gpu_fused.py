@@ -64,10 +64,12 @@ def test_fused_not_used_when_grad_is_recorded():
 def test_unsupported_shapes_fall_to_library_path():
     from hierarchicalgnn_amd import fused, make_mlp
     with torch.no_grad():
-        enc = make_mlp(3, 64, 32, 3, layer_norm=True).cuda()          # node encoder: K=3
-        assert not fused.supported(enc, [(torch.randn(9, 3).cuda(), None)], None)
-        head = make_mlp(64, 64, 1, 3, layer_norm=True, output_activation=None).cuda()
-        assert not fused.supported(head, [(torch.randn(9, 64).cuda(), None)], None)
+        odd = make_mlp(24, 64, 32, 3, layer_norm=True).cuda()         # K=24: neither %16 nor <= 16
+        assert not fused.supported(odd, [(torch.randn(9, 24).cuda(), None)], None)
+        noln = make_mlp(32, 64, 32, 2, layer_norm=False).cuda()
+        assert not fused.supported(noln, [(torch.randn(9, 32).cuda(), None)], None)
+        sup = make_mlp(32, 64, 24, 3, layer_norm=True).cuda()         # supernode encoder: out = L - emb_dim
+        assert not fused.supported(sup, [(torch.randn(9, 32).cuda(), None)], None)
 
 
 @pytest.mark.parametrize("latent", [32, 128])
@@ -131,3 +133,53 @@ def test_fused_vs_unfused_at_baseline_width():
         finally:
             fused.set_enabled(True)
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL
+
+
+@pytest.mark.parametrize("L,kind", [(32, "node_enc"), (128, "edge_enc"), (256, "edge_enc"), (64, "node_enc")])
+def test_fused_encoders_small_k(L, kind):
+    """node / edge encoders (IN.py:26-46): K = 3 / 6 spatial coordinates, gathered 12-byte rows"""
+    from hierarchicalgnn_amd import fused, make_mlp
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(L)
+    N, M = 300, 1111
+    x = torch.rand(N, 3, generator=g) * 2 - 1
+    i0 = torch.randint(0, N, (M,), generator=g)
+    i1 = torch.randint(0, N, (M,), generator=g)
+    torch.manual_seed(L + 1)
+    if kind == "edge_enc":
+        net = make_mlp(6, 2 * L, L, 2, layer_norm=True, output_activation="GELU", hidden_activation="GELU")
+        segs_cpu, layers, xin = [(x, i0), (x, i1)], 2, torch.cat([x[i0], x[i1]], 1)
+    else:
+        net = make_mlp(3, 2 * L, L, 3, layer_norm=True, output_activation="GELU", hidden_activation="GELU")
+        segs_cpu, layers, xin = [(x, None)], 3, x
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = O.mlp_apply(sd, "", xin, layers, "GELU", "GELU", True)
+    net = net.cuda()
+    segs = [(t.cuda(), None if i is None else i.cuda()) for t, i in segs_cpu]
+    with torch.no_grad():
+        assert fused.supported(net, segs, None)
+        out = fused.fused_concat_mlp(net, segs, None)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
+
+
+@pytest.mark.parametrize("L,act", [(32, "GELU"), (128, "GELU"), (128, "Tanh"), (256, "Tanh"), (64, "ReLU")])
+def test_fused_heads_width_one(L, act):
+    """classifier heads 2L -> H -> H -> 1, plain last layer (IN.py:107-115; HGNN_GMM.py:313-321)"""
+    from hierarchicalgnn_amd import fused, make_mlp
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(L + 7)
+    M = 777
+    torch.manual_seed(L)
+    net = make_mlp(2 * L, 2 * L, 1, 3, layer_norm=True, output_activation=None, hidden_activation=act)
+    a = torch.randn(M, L, generator=g)
+    tab = torch.randn(50, L, generator=g)
+    idx = torch.randint(0, 50, (M,), generator=g)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = O.mlp_apply(sd, "", torch.cat([a, tab[idx]], 1), 3, act, None, True)
+    net = net.cuda()
+    segs = [(a.cuda(), None), (tab.cuda(), idx.cuda())]
+    with torch.no_grad():
+        assert fused.supported(net, segs, None)
+        out = fused.fused_concat_mlp(net, segs, None)
+    assert out.shape == (M, 1)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
