@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HgnnPlan(Structure):
@@ -44,6 +44,7 @@ class HgnnMlpDesc(Structure):
         ("M", c_int64),
         ("w0_cols", c_int32),
         ("w_last_rows", c_int32),
+        ("save_pre", c_void_p * 3),
     ]
 
 

@@ -31,7 +31,6 @@ namespace hgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-int g_opt_mlp_stagger = 0;  // set through hgnn_set_option("mlp_stagger", n)
 int g_opt_mlp_ablate = 0;   // set through hgnn_set_option("mlp_ablate", bits): DIAGNOSTIC, wrong results
 
 struct MlpArgs {
@@ -50,10 +49,9 @@ struct MlpArgs {
     float eps;
     const float* skip;
     float* out;
+    float* save_pre[3];  // optional [M, width_l] dumps of each layer's pre-LayerNorm output (training)
     long long M;
     int ablate;        // DIAGNOSTIC ONLY (wrong results): 1 = skip LN/act, 2 = skip weight DMA, 4 = skip barriers
-    int stagger;       // one-time start delay (x s_sleep 127) of the second resident workgroup per CU
-    int stagger_from;  // first block index that is delayed (= number of CUs)
 };
 
 // Activations.  v_mfma_f32_16x16x4_f32 runs on the SIMD's fp32 vector ALUs (its rate IS the VALU FMA
@@ -281,6 +279,16 @@ __device__ __forceinline__ void store_out(const f32x4 (&acc)[NT], const MlpArgs&
     }
 }
 
+// training: dump a layer's pre-LayerNorm activations z[e][f] (what the hand-written backward in
+// fused.py needs; the hidden activations themselves are recomputed from it, never stored)
+template <int NT>
+__device__ __forceinline__ void dump_pre(const f32x4 (&acc)[NT], float* base, long long e, bool valid, int g) {
+    if (base == nullptr || !valid) return;  // base is wave-uniform
+    float* op = base + (size_t)e * (NT * 16) + g * 4;
+#pragma unroll
+    for (int T = 0; T < NT; ++T) *(f32x4*)(op + T * 16) = acc[T];
+}
+
 // NT1/NT2/NT3: 16-feature tiles of layer 1 / 2 / 3 outputs (NT3 == 0: two-layer MLP)
 // ACT_H / ACT_O: activation of the hidden layers / of the last layer (HGNN_ACT_*), or -1 = read
 // it from the descriptor per element (keeps rare combinations working without an instantiation)
@@ -294,16 +302,6 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     const int g = lane >> 4;
     const long long e = (long long)blockIdx.x * 64 + wave * 16 + ei;
     const bool valid = e < a.M;
-    // Two workgroups share a CU.  Dispatched together they would run in lockstep: both in their
-    // MFMA loops, then both in their LayerNorm/GELU epilogues (matrix pipe idle).  Delaying the
-    // second wave of workgroups once, by about half a workgroup's lifetime, keeps one block's VALU
-    // epilogue under the other's MFMAs for the rest of the launch (speed only, never correctness).
-    if (a.stagger > 0 && (int)blockIdx.x < 2 * a.stagger_from) {
-        // HW_REG_HW_ID[3:0] = wave slot on this SIMD: co-resident waves differ in it (speed only)
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-        if (slot & 1u)
-            for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const long long er = valid ? e : 0;
 
     // per-lane row start of every input segment (the gather is folded in here).  The X stream is
@@ -387,6 +385,7 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     // epilogue would otherwise starve the co-resident workgroup's MFMA stream whenever it is the
     // older of the two.  Epilogues run at priority 0, MFMA loops at priority 2.
     __builtin_amdgcn_s_setprio(0);
+    dump_pre<NT1>(acc1, a.save_pre[0], e, valid, g);
     if (!(a.ablate & 1)) layernorm_act<NT1, ACT_H>(acc1, a.lnw[0], a.lnb[0], a.act[0], a.eps, g);
     __builtin_amdgcn_s_setprio(2);
 
@@ -395,6 +394,7 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     init_bias<NT2>(acc2, a.b[1], g);
     dense_from_regs<NT1, NT2>(acc1, acc2, a.W[1], lds, wave, lane, a.ablate);
     __builtin_amdgcn_s_setprio(0);
+    dump_pre<NT2>(acc2, a.save_pre[1], e, valid, g);
     if (!(a.ablate & 1))
         layernorm_act<NT2, (NT3 == 0 ? ACT_O : ACT_H), !(PLAIN_LAST && NT3 == 0)>(acc2, a.lnw[1], a.lnb[1], a.act[1],
                                                                                   a.eps, g);
@@ -406,6 +406,7 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
         __builtin_amdgcn_s_setprio(2);
         dense_from_regs<NT2, NT3>(acc2, acc3, a.W[2], lds, wave, lane, a.ablate);
         __builtin_amdgcn_s_setprio(0);
+        dump_pre<NT3>(acc3, a.save_pre[2], e, valid, g);
         if (!(a.ablate & 1)) layernorm_act<NT3, ACT_O, !PLAIN_LAST>(acc3, a.lnw[2], a.lnb[2], a.act[2], a.eps, g);
         store_out<NT3>(acc3, a, e, valid, g);
     }
@@ -529,8 +530,12 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
         if (on && a.lnw[l] == nullptr) a.lnw[l] = a.lnb[l] = a.b[l];  // never dereferenced (plain layer)
     }
     a.ablate = g_opt_mlp_ablate;
-    a.stagger = g_opt_mlp_stagger;
-    a.stagger_from = 256;
+    for (int l = 0; l < 3; ++l) {
+        a.save_pre[l] = l < d->n_layers ? d->save_pre[l] : nullptr;
+        HGNN_REQUIRE((uintptr_t)a.save_pre[l] % 16 == 0, "hgnn_mlp_forward_f32: save_pre[%d] must be 16-byte aligned", l);
+    }
+    HGNN_REQUIRE(!(is_head(d) && (d->save_pre[0] || d->save_pre[1] || d->save_pre[2])),
+                 "hgnn_mlp_forward_f32: save_pre is not available for width-1 heads");
     a.eps = d->ln_eps;
     a.skip = d->skip;
     a.out = out;

@@ -23,7 +23,6 @@ namespace hgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-extern int g_opt_mlp_stagger;  // mlp_fused.hip
 extern int g_opt_mlp_ablate;
 
 static int g_opt_nt_loads = 1;   // non-temporal loads for once-read source rows
@@ -464,7 +463,7 @@ static int dispatch_seg(const SegArgs& a, hipStream_t s) {
     if (nvec <= 4) launch_seg<4, 1, 4, W, RS, TAG>(a, s);
     else if (nvec <= 8) launch_seg<8, 1, 4, W, RS, TAG>(a, s);
     else if (nvec <= 16) launch_seg<16, 1, 4, W, RS, TAG>(a, s);
-    else if (nvec <= 32) launch_seg<32, 1, 4, W, RS, TAG>(a, s);
+    else if (nvec <= 32) launch_seg<32, 1, 4, W, RS, TAG>(a, s);  // (U8 / 16-wave variants: within 1 %)
     else if (nvec <= 64) {
         if (!W && !RS) launch_seg_tuned<TAG>(a, s);
         else launch_seg<64, 1, 8, W, RS, TAG>(a, s);
@@ -491,7 +490,6 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     else if (!strcmp(name, "seg_unroll")) g_opt_seg_unroll = value;
     else if (!strcmp(name, "seg_wpb")) g_opt_seg_wpb = value;
     else if (!strcmp(name, "seg_xcd")) g_opt_seg_xcd = value;
-    else if (!strcmp(name, "mlp_stagger")) g_opt_mlp_stagger = value < 0 ? 0 : value;
     else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 7;
     else {
         set_error("hgnn_set_option: unknown option '%s'", name);

@@ -21,13 +21,21 @@ from .plan import get_index32
 
 _ACT = {nn.GELU: 1, nn.Tanh: 2, nn.ReLU: 3}
 _enabled = True
-stats = {"fused_calls": 0}
+# The differentiable variant (kernel forward + hand-written backward) is OPT-IN: measured on MI355X at
+# L=256, M=2M it is 2 % slower than autograd through the library path (112.0 vs 109.8 ms per
+# checkpointed cell step; 92.2 vs 90.5 ms without checkpointing) because the step is dominated by
+# library GEMMs either way (profiles/r01_train_step_and_hgnn_cell_L256.json).  It is kept, tested, as
+# the scaffold for an MFMA backward.
+_train_enabled = False
+stats = {"fused_calls": 0, "fused_train_calls": 0}
 
 
-def set_enabled(flag: bool):
-    """switch the fused kernel off/on (A/B measurements, debugging)"""
-    global _enabled
+def set_enabled(flag: bool, train: bool = None):
+    """switch the fused forward kernel off/on (A/B measurements, debugging); `train=True` also
+    opts in to the differentiable variant (off by default, see above)"""
+    global _enabled, _train_enabled
     _enabled = bool(flag)
+    _train_enabled = bool(train) if train is not None else False
 
 
 def _parse(net: nn.Sequential):
@@ -172,3 +180,147 @@ def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
     del keep
     stats["fused_calls"] += 1
     return out
+
+
+# --------------------------------------------------------------------------- training variant
+class _FusedMLPTrain(torch.autograd.Function):
+    """Differentiable fused MLP.  Forward = the same MFMA kernel, additionally dumping each layer's
+    pre-LayerNorm output z_l (``save_pre``).  Backward is written out by hand: LayerNorm / activation
+    are re-derived from z_l with elementwise ATen kernels, data and weight gradients are library
+    GEMMs, and the gradients of gathered segments go back through the atomics-free segmented
+    reduce.  Compared with autograd through the unfused path this skips the second forward's GEMMs,
+    the [M,3L] concat and the gathered copies; with 288 GB of HBM the reference's checkpointing can
+    also be switched off (hparams["checkpointing"]=False) and the dumps kept instead."""
+
+    @staticmethod
+    def forward(ctx, net, indices, has_skip, *tensors):
+        n_seg = len(indices)
+        tables = list(tensors[:n_seg])
+        skip = tensors[n_seg] if has_skip else None
+        params = tensors[n_seg + (1 if has_skip else 0):]
+        segments = [(t, i) for t, i in zip(tables, indices)]
+        desc = _descriptor(net, segments, skip)
+        if desc is None:
+            raise RuntimeError("fused_concat_mlp_train: unsupported arguments (call supported_train() first)")
+        d, keep, M, n_out = desc
+        n = int(d.n_layers)
+        dev = tables[0].device
+        zs = [torch.empty((M, int(d.width[l + 1])), dtype=torch.float32, device=dev) for l in range(n)]
+        for l in range(n):
+            d.save_pre[l] = zs[l].data_ptr() if M else None
+        out = torch.empty((M, n_out), dtype=torch.float32, device=dev)
+        if M:
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().hgnn_mlp_forward_f32(ctypes.byref(d), _lib.ptr(out),
+                                                            _lib.current_stream(dev)), "hgnn_mlp_forward_f32")
+        del keep
+        stats["fused_train_calls"] += 1
+        ctx.indices, ctx.has_skip, ctx.n = indices, has_skip, n
+        ctx.acts = [int(d.act[l]) for l in range(n)]
+        ctx.eps = float(d.ln_eps)
+        ctx.save_for_backward(*tables, *params, *zs)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from .ops import _seg_reduce, _spread_rows
+        from .plan import get_plan
+        n, indices = ctx.n, ctx.indices
+        n_seg = len(indices)
+        saved = ctx.saved_tensors
+        tables = saved[:n_seg]
+        params = saved[n_seg:n_seg + 4 * n]
+        zs = saved[n_seg + 4 * n:]
+        W = [params[4 * l] for l in range(n)]
+        lnw = [params[4 * l + 2] for l in range(n)]
+        lnb = [params[4 * l + 3] for l in range(n)]
+        aten = torch.ops.aten
+        g = grad_out.contiguous()
+        # re-derive y_l = LN(z_l) (+ statistics) and a_l = act(y_l): elementwise kernels only
+        ys, means, rstds, outs = [], [], [], []
+        for l in range(n):
+            y, mean, rstd = torch.native_layer_norm(zs[l], [zs[l].shape[1]], lnw[l], lnb[l], ctx.eps)
+            ys.append(y)
+            means.append(mean)
+            rstds.append(rstd)
+            code = ctx.acts[l]
+            if l < n - 1 or code == 2:
+                outs.append(torch.tanh(y) if code == 2 else (torch.nn.functional.gelu(y) if code == 1
+                            else (torch.relu(y) if code == 3 else y)))
+            else:
+                outs.append(None)
+        grads_params = [None] * (4 * n)
+        grads_tables = [None] * n_seg
+        da = g
+        for l in range(n - 1, -1, -1):
+            code = ctx.acts[l]
+            if code == 1:
+                dy = aten.gelu_backward(da, ys[l], approximate="none")
+            elif code == 2:
+                dy = aten.tanh_backward(da, outs[l])
+            elif code == 3:
+                dy = da * (ys[l] > 0)
+            else:
+                dy = da
+            dz, dlw, dlb = aten.native_layer_norm_backward(dy, zs[l], [zs[l].shape[1]], means[l], rstds[l],
+                                                           lnw[l], lnb[l], [True, True, True])
+            ys[l] = None
+            grads_params[4 * l + 1] = dz.sum(dim=0)
+            grads_params[4 * l + 2] = dlw
+            grads_params[4 * l + 3] = dlb
+            if l > 0:
+                grads_params[4 * l] = dz.t() @ outs[l - 1]
+                da = dz @ W[l]
+                outs[l - 1] = None
+            else:
+                # weight gradient of the first layer as ONE GEMM over the concatenated input rows
+                # (three N=L GEMMs picked a 256x32 tile and ran 1.7x longer); the [M,K] concat is
+                # transient and only exists during this backward
+                plans, parts = [], []
+                for s_i in range(n_seg):
+                    idx = indices[s_i]
+                    tab = tables[s_i].contiguous()
+                    plan = get_plan(idx, int(tab.shape[0])) if idx is not None else None
+                    plans.append(plan)
+                    parts.append(tab if idx is None else _spread_rows(plan, tab))
+                x_cat = parts[0] if n_seg == 1 else torch.cat(parts, dim=1)
+                del parts
+                dW = dz.t() @ x_cat
+                del x_cat
+                col = 0
+                for s_i in range(n_seg):
+                    w_s = int(tables[s_i].shape[1])
+                    if ctx.needs_input_grad[3 + s_i]:
+                        drows = dz @ W[0][:, col:col + w_s]
+                        grads_tables[s_i] = drows if plans[s_i] is None else _seg_reduce(plans[s_i], drows, None, None)
+                    col += w_s
+                grads_params[0] = dW
+        grad_skip = [g] if ctx.has_skip else []
+        return (None, None, None, *grads_tables, *grad_skip, *grads_params)
+
+
+def supported_train(net, segments, skip) -> bool:
+    """differentiable fused path: cell networks (LayerNorm on every layer, 16-aligned segments)"""
+    if not _train_enabled or not torch.is_grad_enabled():
+        return False
+    try:
+        desc = _descriptor(net, segments, skip)
+    except RuntimeError:
+        return False
+    if desc is None:
+        return False
+    d = desc[0]
+    if int(d.w0_cols) != 0 or int(d.w_last_rows) != 0:
+        return False
+    return bool(_lib.load().hgnn_mlp_supported(ctypes.byref(d)))
+
+
+def fused_concat_mlp_train(net, segments, skip: Optional[torch.Tensor]):
+    layers = _parse(net)
+    params = []
+    for lin, ln, _ in layers:
+        params += [lin.weight, lin.bias, ln.weight, ln.bias]
+    tables = [t for t, _ in segments]
+    indices = tuple(i for _, i in segments)
+    extra = [skip] if skip is not None else []
+    return _FusedMLPTrain.apply(net, indices, skip is not None, *tables, *extra, *params)

@@ -7,8 +7,9 @@ where each segment is either a tensor or a row gather ``table[index]``
 ``concat_mlp`` is the single entry point the cells use.  Gathers run in the HIP
 row-gather kernel (backward: atomics-free segmented reduce).  The dense layers
 are evaluated by the fused fp32-MFMA kernel when the shape is supported
-(``fused.py``), otherwise by the library GEMM path (rocBLAS through ATen) --
-both on the GPU; neither is a CPU fallback.
+(``fused.py``: forward-only when autograd is off, a differentiable variant with a
+hand-written backward when it records), otherwise by the library GEMM path (rocBLAS
+through ATen) -- all on the GPU; none is a CPU fallback.
 """
 from __future__ import annotations
 
@@ -26,6 +27,8 @@ def concat_mlp(net: nn.Sequential, segments: Sequence[Segment], skip: Optional[t
     from . import fused
     if fused.supported(net, segments, skip):
         return fused.fused_concat_mlp(net, segments, skip)
+    if fused.supported_train(net, segments, skip):
+        return fused.fused_concat_mlp_train(net, segments, skip)
     parts: List[torch.Tensor] = []
     for table, index in segments:
         parts.append(table if index is None else gather_rows(table, index))

@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 7
+#define HGNN_ABI_VERSION 8
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -103,7 +103,6 @@ int hgnn_sizeof_mlp_desc(void);
 
 /* Process-wide switches for A/B measurements:
  *   "nt_loads", "nt_stores", "seg_unroll", "seg_wpb", "seg_xcd"   K1..K6 launch shape / cache policy
- *   "mlp_stagger"  one-time start delay (x s_sleep 127) of every second resident wave slot
  *   "mlp_ablate"   DIAGNOSTIC bits, results are WRONG: 1 skip LayerNorm/act, 2 skip weight DMA,
  *                  4 skip barriers (used to price those parts; tools/tune_mlp.py) */
 int hgnn_set_option(const char* name, int value);
@@ -210,6 +209,9 @@ typedef struct hgnn_mlp_desc {
                                   * multiple of 16 (node / edge encoders, K = 3 / 6: IN.py:26-46)  */
     int32_t w_last_rows;         /* rows stored in the last W / b: 0 = width[n]; must be 32 (zero
                                   * padded) for a width-1 head (IN.py:107-115, HGNN_GMM.py:313-321) */
+    float* save_pre[3];          /* optional: [M, width[l+1]] buffers that receive layer l's output
+                                  * BEFORE LayerNorm/activation (what a backward pass needs; hidden
+                                  * activations are recomputed from it).  NULL = not saved.         */
 } hgnn_mlp_desc;
 
 /* 1 if hgnn_mlp_forward_f32 has an instantiation for this descriptor (host-only check):

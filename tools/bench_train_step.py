@@ -49,9 +49,15 @@ def train_step():
     edges.grad = None
 
 
-for name, on in (("fused_first_pass", True), ("library_only", False)):
-    fused.set_enabled(on)
-    res[f"ignn_cell_fwd_bwd_checkpointed_{name}_ms"] = timeit(train_step, 3, 1)
+for ckpt in (True, False):
+    cell._ckpt = ckpt
+    for name, fwd, trn in (("fused_fwd+fused_train", True, True), ("fused_fwd+library_bwd", True, False),
+                           ("library_only", False, False)):
+        fused.set_enabled(fwd, train=trn)
+        res[f"ignn_cell_fwd_bwd_{'checkpointed' if ckpt else 'no_checkpoint'}_{name}_ms"] = timeit(train_step, 3, 1)
+        res[f"peak_mem_GB_{'ckpt' if ckpt else 'nockpt'}_{name}"] = torch.cuda.max_memory_allocated() / 2**30
+        torch.cuda.reset_peak_memory_stats()
+cell._ckpt = True
 fused.set_enabled(True)
 
 S = 10_000
