@@ -149,9 +149,97 @@ def _descriptor(net, segments, skip):
     return d, keep, M, n_out
 
 
+def _kslot_perm(k: int, device) -> torch.Tensor:
+    """column order of W_{l>=1} for the bf16 kernel: slot 32c+8g+j <- feature 32c+(j<4 ? 4g+j : 16+4g+j-4)"""
+    c = torch.arange(k // 32, device=device).view(-1, 1, 1) * 32
+    g = torch.arange(4, device=device).view(1, -1, 1)
+    j = torch.arange(8, device=device).view(1, 1, -1)
+    feat = c + torch.where(j < 4, 4 * g + j, 16 + 4 * g + j - 4)
+    return feat.reshape(-1)
+
+
+def _descriptor_bf16(net, segments, skip):
+    """descriptor for hgnn_mlp_forward_bf16: bf16 rows, bf16 (slot-ordered) weights, fp32 bias / LayerNorm"""
+    layers = _parse(net)
+    if layers is None or len(layers) not in (2, 3) or not (1 <= len(segments) <= 3):
+        return None
+    if any(ln is None for _, ln, _ in layers):
+        return None
+    d = _lib.HgnnMlpDesc()
+    keep = []
+    d.n_seg = len(segments)
+    M = None
+    for i, (table, index) in enumerate(segments):
+        if table.dim() != 2 or not table.is_cuda or table.dtype != torch.bfloat16:
+            return None
+        t = table if table.is_contiguous() else table.contiguous()
+        keep.append(t)
+        rows = int(index.numel()) if index is not None else int(t.shape[0])
+        if M is None:
+            M = rows
+        elif M != rows:
+            return None
+        d.seg_table[i] = t.data_ptr()
+        d.seg_width[i] = int(t.shape[1])
+        if index is not None:
+            i32 = get_index32(index, int(t.shape[0]))
+            keep.append(i32)
+            d.seg_index[i] = i32.data_ptr() if i32.numel() else None
+        else:
+            d.seg_index[i] = None
+    n = len(layers)
+    d.n_layers = n
+    d.width[0] = sum(int(t.shape[1]) for t, _ in segments)
+    eps = None
+    for l, (lin, ln, act) in enumerate(layers):
+        if lin.in_features != d.width[l] or not lin.weight.is_cuda:
+            return None
+        W = lin.weight.detach()
+        if l > 0:
+            if lin.in_features % 32:
+                return None
+            W = W[:, _kslot_perm(lin.in_features, W.device)]
+        W = W.to(torch.bfloat16).contiguous()
+        small = [p.detach().float().contiguous() for p in (lin.bias, ln.weight, ln.bias)]
+        keep += [W] + small
+        d.W[l], d.b[l], d.ln_w[l], d.ln_b[l] = W.data_ptr(), small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr()
+        d.width[l + 1] = lin.out_features
+        d.act[l] = act
+        if eps is None:
+            eps = ln.eps
+        elif eps != ln.eps:
+            return None
+    d.ln_eps = float(eps)
+    n_out = int(d.width[n])
+    if skip is not None:
+        if tuple(skip.shape) != (M, n_out) or not skip.is_cuda or skip.dtype != torch.bfloat16:
+            return None
+        sk = skip if skip.is_contiguous() else skip.contiguous()
+        keep.append(sk)
+        d.skip = sk.data_ptr()
+    else:
+        d.skip = None
+    d.M = M
+    return d, keep, M, n_out
+
+
+def _is_bf16(segments) -> bool:
+    return all(t.dtype == torch.bfloat16 for t, _ in segments)
+
+
 def supported(net, segments, skip) -> bool:
     if not _enabled:
         return False
+    if _is_bf16(segments):
+        if torch.is_grad_enabled():
+            tensors = [t for t, _ in segments] + ([skip] if skip is not None else []) + list(net.parameters())
+            if any(t.requires_grad for t in tensors):
+                return False
+        try:
+            desc = _descriptor_bf16(net, segments, skip)
+        except RuntimeError:
+            return False
+        return desc is not None and bool(_lib.load().hgnn_mlp_supported_bf16(ctypes.byref(desc[0])))
     if torch.is_grad_enabled():
         tensors = [t for t, _ in segments] + ([skip] if skip is not None else []) + list(net.parameters())
         if any(t.requires_grad for t in tensors):
@@ -166,17 +254,23 @@ def supported(net, segments, skip) -> bool:
 
 
 def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
-    desc = _descriptor(net, segments, skip)
+    bf16 = _is_bf16(segments)
+    desc = _descriptor_bf16(net, segments, skip) if bf16 else _descriptor(net, segments, skip)
     if desc is None:
         raise RuntimeError("fused_concat_mlp: unsupported arguments (call supported() first)")
     d, keep, M, n_out = desc
     dev = segments[0][0].device
-    out = torch.empty((M, n_out), dtype=torch.float32, device=dev)
+    out = torch.empty((M, n_out), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
     if M == 0:
         return out
+    lib = _lib.load()
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().hgnn_mlp_forward_f32(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
-                   "hgnn_mlp_forward_f32")
+        if bf16:
+            _lib.check(lib.hgnn_mlp_forward_bf16(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
+                       "hgnn_mlp_forward_bf16")
+        else:
+            _lib.check(lib.hgnn_mlp_forward_f32(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
+                       "hgnn_mlp_forward_f32")
     del keep
     stats["fused_calls"] += 1
     return out

@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 8
+#define HGNN_ABI_VERSION 9
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -226,6 +226,15 @@ int hgnn_mlp_supported(const hgnn_mlp_desc* d);
 /* out[M, L] = MLP(cat_i seg_i[idx_i]) (+ skip).  No workspace; hidden activations stay in
  * registers.  Negative gather indices read row 0 (callers validate indices at plan build). */
 int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_stream_t stream);
+
+/* bf16 variant (BASELINE config 4 dtype) on v_mfma_f32_16x16x32_bf16.  Same descriptor, read as:
+ * seg_table / skip / out = bf16 rows; W[l] = bf16 [out][in] row-major, and for l >= 1 with its
+ * COLUMNS stored in MFMA k-slot order: column 32c + 8g + j holds input feature
+ * 32c + (j < 4 ? 4g + j : 16 + 4g + j - 4)  (c = k-block, g = 0..3, j = 0..7);
+ * b / ln_w / ln_b fp32; accumulation and LayerNorm in fp32.  Supported: K -> 2L (-> 2L) -> L,
+ * LayerNorm on every layer, L in {32, 64, 128, 256}, every segment a multiple of 32 wide. */
+int hgnn_mlp_supported_bf16(const hgnn_mlp_desc* d);
+int hgnn_mlp_forward_bf16(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

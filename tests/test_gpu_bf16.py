@@ -70,3 +70,36 @@ def test_bf16_unsupported_width_is_an_error():
     import hierarchicalgnn_amd as H
     with pytest.raises(RuntimeError, match="multiple of 8"):
         H.scatter_add(torch.zeros(10, 12).bfloat16().cuda(), torch.zeros(10, dtype=torch.long).cuda(), dim_size=2)
+
+
+@pytest.mark.parametrize("L,layers,nseg,M", [(32, 2, 3, 700), (64, 2, 3, 513), (128, 2, 3, 300), (256, 2, 3, 200),
+                                             (64, 3, 2, 400), (128, 3, 3, 129), (256, 3, 2, 90)])
+def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M):
+    """bf16-MFMA fused MLP: against the fp32 oracle evaluated on the bf16-rounded inputs and weights"""
+    from hierarchicalgnn_amd import fused, make_mlp
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(L * 10 + layers)
+    out_act = "Tanh" if layers == 2 else "GELU"
+    torch.manual_seed(L + layers)
+    net = make_mlp(nseg * L, 2 * L, L, layers, layer_norm=True, output_activation=out_act, hidden_activation="GELU")
+    for p in net.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.2 * torch.randn_like(p))
+    n_tab = 97
+    table = torch.randn(n_tab, L, generator=g).bfloat16()
+    idx0 = torch.randint(0, n_tab, (M,), generator=g)
+    idx1 = torch.randint(0, n_tab, (M,), generator=g)
+    direct = torch.randn(M, L, generator=g).bfloat16()
+    segs_cpu = [(table, idx0), (table, idx1), (direct, None)][3 - nseg:]
+    x = torch.cat([t.float() if i is None else t.float()[i] for t, i in segs_cpu], dim=1)
+    sd = {k: (v.detach().bfloat16().float() if k.endswith("weight") and v.dim() == 2 else v.detach())
+          for k, v in net.state_dict().items()}
+    ref = O.mlp_apply(sd, "", x, layers, "GELU", out_act, True) + direct.float()
+    net = net.cuda()
+    segs = [(t.cuda(), None if i is None else i.cuda()) for t, i in segs_cpu]
+    with torch.no_grad():
+        assert fused.supported(net, segs, segs[-1][0])
+        out = fused.fused_concat_mlp(net, segs, segs[-1][0])
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    # hidden activations are rounded to bf16 between layers: a few bf16 ulps at the output scale
+    assert rel_err(out.float().cpu().numpy(), ref.numpy()) <= 4 * BF16_TOL
