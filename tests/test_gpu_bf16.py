@@ -103,3 +103,26 @@ def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M):
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
     # hidden activations are rounded to bf16 between layers: a few bf16 ulps at the output scale
     assert rel_err(out.float().cpu().numpy(), ref.numpy()) <= 4 * BF16_TOL
+
+
+@pytest.mark.parametrize("latent", [32, 128])
+def test_interaction_cell_bf16_tracks_the_fp32_reference(latent):
+    """whole InteractionGNNCell in bf16 (bf16 aggregation kernels + bf16-MFMA MLPs, fp32 master weights)
+    against the reference's fp32 outputs: bf16-level agreement"""
+    import numpy as np
+    import hierarchicalgnn_amd as H
+    from hierarchicalgnn_amd import fused
+    from conftest import load_golden
+    z = load_golden(f"ignn_cell_L{latent}.npz")
+    hp = dict(latent=latent, hidden=2 * latent, nb_edge_layer=2, nb_node_layer=3, layernorm=True,
+              hidden_activation="GELU")
+    cell = H.InteractionGNNCell(hp)
+    cell.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")})
+    cell = cell.cuda()
+    n0 = fused.stats["fused_calls"]
+    with torch.no_grad():
+        on, oe = cell(torch.from_numpy(z["nodes"]).cuda().bfloat16(), torch.from_numpy(z["edges"]).cuda().bfloat16(),
+                      torch.from_numpy(z["graph"]).cuda())
+    assert fused.stats["fused_calls"] == n0 + 2 and on.dtype == torch.bfloat16
+    assert rel_err(on.float().cpu().numpy(), z["out_nodes"]) <= 6 * BF16_TOL
+    assert rel_err(oe.float().cpu().numpy(), z["out_edges"]) <= 6 * BF16_TOL
