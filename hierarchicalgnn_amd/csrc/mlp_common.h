@@ -68,7 +68,7 @@ __device__ __forceinline__ void dma_piece(const char* src, unsigned lds_addr) {
         "global_load_lds_dwordx4 %0, off"
         :
         : "v"(src), "s"(lds_addr)
-        : "memory", "m0");
+        : "memory");  // m0 is a reserved register: hipcc re-materialises it before each of its own uses
 }
 
 __device__ __forceinline__ unsigned lds_addr_of(float* p) {
