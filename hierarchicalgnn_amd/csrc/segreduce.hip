@@ -32,7 +32,8 @@ __device__ __forceinline__ f32x4 ld4(const float* p, bool nt) {
     return nt ? __builtin_nontemporal_load((const f32x4*)p) : *(const f32x4*)p;
 }
 
-// TAG distinguishes the main pass (0) from the partial-sum combine pass (1) in profiles.
+// TAG distinguishes the main pass (0), the partial-sum combine pass (1) and the main pass on a
+// destination-sorted index (2, identity row ids = streaming reads) in profiles.
 template <int RL, int VPL, int U, bool HAS_W, bool HAS_RS, bool NT, int TAG, int WPB, bool XCD>
 __global__ __launch_bounds__(WPB * 64) void k_seg_reduce(
     const float* __restrict__ src, int F, int nvec, const int32_t* __restrict__ src_row,
@@ -532,6 +533,8 @@ extern "C" int hgnn_segment_reduce_f32(const hgnn_plan* plan, const float* src, 
     else if (row_scale) {
         set_error("hgnn_segment_reduce_f32: row_scale requires weight");
         return HGNN_ERR_UNSUPPORTED;
+    } else if (plan->src_row == nullptr) {
+        rc = dispatch_seg<false, false, 2>(a, stream);  // TAG 2: sorted-layout (streaming) launches, named apart in profiles
     } else rc = dispatch_seg<false, false, 0>(a, stream);
     if (rc != HGNN_OK) return rc;
     // second pass: sum the partial rows of split destinations, in chunk order
