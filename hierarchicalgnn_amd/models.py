@@ -150,6 +150,11 @@ class HierarchicalGNNBlock(nn.Module):
         self.hparams = hparams
         self._ckpt = bool(hparams.get("checkpointing", True))
 
+    def clustering(self, embeddings, graph):
+        """HGNN_GMM.py:184-234 on the GPU (clustering.py): cluster id per hit, -1 = unclustered"""
+        from .clustering import gmm_edge_clustering
+        return gmm_edge_clustering(embeddings, graph, self.score_cut, self.hparams, self.training)
+
     def hierarchy_from_clusters(self, embeddings, clusters):
         """HGNN_GMM.py:251-260 given the cluster label of every hit (-1 = unclustered): centroids
         (scatter_mean, K8), L2-normalise, kNN super graph (symmetrised, sigmoid weights) and
@@ -190,8 +195,10 @@ class HierarchicalGNNBlock(nn.Module):
 
 
 class BC_MessagePassing(nn.Module):
-    """The tensor arithmetic of BC_HierarchicalGNN_GMM (HGNN_GMM.py:300-346) around a given
-    hierarchy: IGNN block -> (hierarchy supplied by the caller) -> HGNN block -> bipartite head."""
+    """BC_HierarchicalGNN_GMM (HGNN_GMM.py:300-346) without its Lightning base: IGNN block ->
+    hierarchy decision (GPU clustering + kNN graphs) -> HGNN block -> bipartite head.  ``forward``
+    runs all of it; ``embed`` / ``hgnn_block(...)`` / ``score`` expose the stages so that a caller
+    can also supply its own hierarchy."""
 
     def __init__(self, hparams):
         super().__init__()
@@ -212,6 +219,14 @@ class BC_MessagePassing(nn.Module):
         directed_graph = torch.cat([graph, graph.flip(0)], dim=1)
         emb, nodes, edges, directed_graph, order = self.ignn_block.run(x, directed_graph, restore_order)
         return directed_graph, emb, nodes, edges, order
+
+    def forward(self, x, graph):
+        """HGNN_GMM.py:323-346: returns (bipartite_graph[2,B], bipartite_scores[B], embeddings[N,emb_dim])"""
+        directed, emb, nodes, edges, _ = self.embed(x, graph)
+        clusters = self.hgnn_block.clustering(emb, directed)
+        means, bg, bw, sg, sw, _ = self.hgnn_block.hierarchy_from_clusters(emb, clusters)
+        nodes, supernodes, _, _ = self.hgnn_block(nodes, edges, directed, means, bg, bw, sg, sw)
+        return bg, self.score(nodes, supernodes, bg), emb
 
     def score(self, nodes, supernodes, bipartite_graph):
         """HGNN_GMM.py:342-344"""
