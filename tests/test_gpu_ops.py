@@ -355,3 +355,33 @@ def test_sorted_index_takes_the_streaming_path(H, O):
     idx2 = idx.clone()
     idx2[0], idx2[-1] = idx2[-1].item(), idx2[0].item()
     assert not H.get_plan(idx2.cuda(), N).sorted
+
+
+def test_randomized_shapes_against_oracle(H, O):
+    """40 random (M, N, F, skew, weighting) combinations, forward and backward, incl. tiny and ragged ones"""
+    g = torch.Generator().manual_seed(2024)
+    for trial in range(40):
+        M = int(torch.randint(0, 3000, (1,), generator=g))
+        N = int(torch.randint(1, 400, (1,), generator=g))
+        F = [1, 2, 4, 5, 8, 12, 16, 32, 36, 64, 96, 128, 200, 256, 384, 512][int(torch.randint(0, 16, (1,), generator=g))]
+        src = torch.randn(M, F, generator=g)
+        idx = torch.randint(0, N, (M,), generator=g)
+        if M > 10 and trial % 3 == 0:
+            idx[: M // 2] = int(torch.randint(0, N, (1,), generator=g))       # heavy destination
+        weighted = trial % 2 == 1
+        w = torch.rand(M, 1, generator=g) + 0.1 if weighted else None
+        r = torch.randn(N, F, generator=g)
+        s_ref = src.clone().requires_grad_(True)
+        w_ref = w.clone().requires_grad_(True) if weighted else None
+        ref = O.scatter_add(s_ref * w_ref if weighted else s_ref, idx, 0, N)
+        (ref * r).sum().backward()
+        s = src.cuda().requires_grad_(True)
+        wd = w.cuda().requires_grad_(True) if weighted else None
+        out = H.scatter_add(s, idx.cuda(), dim=0, dim_size=N, weight=wd)
+        (out * r.cuda()).sum().backward()
+        tag = (trial, M, N, F, weighted)
+        assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= TOL, tag
+        if M:
+            assert rel_err(s.grad.cpu().numpy(), s_ref.grad.numpy()) <= TOL, tag
+            if weighted:
+                assert rel_err(wd.grad.cpu().numpy(), w_ref.grad.numpy()) <= TOL, tag
