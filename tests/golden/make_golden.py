@@ -462,8 +462,56 @@ def gen_pool(latent=64):
     print("k5_pool.npz")
 
 
+def gen_dataset(utils):
+    """TrackMLDataset.__getitem__ (utils.py:37-110) run by the reference itself on a synthetic event;
+    torch.load is pointed at an in-memory stand-in for the pickled PyG Data object."""
+    g = torch.Generator().manual_seed(606)
+    n, e = 400, 1500
+
+    class Event(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    def make():
+        pid = torch.randint(0, 60, (n,), generator=g)          # 0 = noise
+        ev = Event(x=torch.randn(n, 3, generator=g), cell_data=torch.randn(n, 4, generator=g), pid=pid,
+                   hid=torch.arange(n), pt=torch.rand(n, generator=g) * 3,
+                   edge_index=torch.randint(0, n - 40, (2, e), generator=g),       # last 40 hits isolated
+                   modulewise_true_edges=torch.randint(0, n, (2, 300), generator=g),
+                   signal_true_edges=torch.randint(0, n, (2, 200), generator=g),
+                   y=torch.randint(0, 2, (e,), generator=g).bool(), y_pid=torch.randint(0, 2, (e,), generator=g).bool(),
+                   primary=torch.randint(0, 2, (n,), generator=g))
+        return ev
+
+    cases = [dict(noise=True, hard_ptcut=0, remove_isolated=True, primary=False, n_hits=5, edge_dropping_ratio=0.),
+             dict(noise=False, hard_ptcut=1.0, remove_isolated=False, primary=True, n_hits=3, edge_dropping_ratio=0.),
+             dict(noise=False, hard_ptcut=0, remove_isolated=True, primary=False, n_hits=5, edge_dropping_ratio=0.)]
+    out = {}
+    real_load = torch.load
+    for ci, hp in enumerate(cases):
+        ev = make()
+        for k, v in ev.items():
+            out[f"case{ci}.in.{k}"] = v.numpy().copy()
+        for k, v in hp.items():
+            out[f"case{ci}.hp.{k}"] = np.array(v)
+        torch.load = lambda *a, **k: ev
+        try:
+            res = utils.TrackMLDataset(["/nonexistent/event0"], hp, stage="train")[0]
+        finally:
+            torch.load = real_load
+        for k, v in res.items():
+            if torch.is_tensor(v):
+                out[f"case{ci}.out.{k}"] = v.numpy().copy()
+    out["n_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(OUT, "dataset_masking.npz"), **out)
+    print("dataset_masking.npz", len(cases), "cases")
+
+
 if __name__ == "__main__":
     gnn_utils, utils, EC, BC = _import_reference()
+    if "--only-dataset" in sys.argv:
+        gen_dataset(utils)
+        sys.exit(0)
     gen_k1_cases()
     gen_pool()
     gen_ignn_cell(gnn_utils, 32, 150, 700, 201)
@@ -472,3 +520,4 @@ if __name__ == "__main__":
     gen_hgnn_cell(gnn_utils, 64, 100, 400, 11, 212)
     gen_ec_in(EC, 32)
     gen_bc_hgnn(BC, 32)
+    gen_dataset(utils)
