@@ -53,35 +53,56 @@ __device__ __forceinline__ u16x8 pack_kblock(const f32x4& t0, const f32x4& t1) {
     return r;
 }
 
+// bf16 epilogue.  bf16 MFMA leaves the fp32 vector ALUs to the epilogue, and at 16x the matrix rate
+// the kernel is VALU-bound (LayerNorm + GELU per hidden element), so the epilogue is written for
+// instruction count at bf16-level accuracy (outputs are rounded to 8 significant bits anyway):
+//   * one-pass LayerNorm statistics (sum and sum of squares in fp32),
+//   * LayerNorm applied as two FMAs,
+//   * GELU in its tanh form folded to x * sigmoid(2u): 7 instructions instead of 17
+//     (|error| vs the erf form <= 5e-4 absolute, below one bf16 ulp of the result).
+__device__ __forceinline__ float gelu_bf16(float x) {
+    // -2*log2(e)*sqrt(2/pi) * (1 + 0.044715 x^2) * x
+    const float t = x * fmaf(-0.10294324f, x * x, -2.30220820f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_b(float x, int act) {
+    const int code = ACT >= 0 ? ACT : act;
+    if (code == HGNN_ACT_GELU) return gelu_bf16(x);
+    return act_apply(x, code);
+}
+
 template <int NT, int ACT>
 __device__ __forceinline__ void layernorm_act_b(f32x4 (&acc)[NT], const float* __restrict__ lnw,
                                                 const float* __restrict__ lnb, int act, float eps, int g) {
     constexpr float inv_n = 1.0f / (float)(NT * 16);
-    float s = 0.f;
-#pragma unroll
-    for (int T = 0; T < NT; ++T) s += (acc[T].x + acc[T].y) + (acc[T].z + acc[T].w);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    const float mean = s * inv_n;
-    float q = 0.f;
+    float s = 0.f, q = 0.f;
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
-        f32x4 d = acc[T] - mean;
-        q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        s += (acc[T].x + acc[T].y) + (acc[T].z + acc[T].w);
+        q = fmaf(acc[T].x, acc[T].x, q);
+        q = fmaf(acc[T].y, acc[T].y, q);
+        q = fmaf(acc[T].z, acc[T].z, q);
+        q = fmaf(acc[T].w, acc[T].w, q);
     }
+    s += __shfl_xor(s, 16);
     q += __shfl_xor(q, 16);
+    s += __shfl_xor(s, 32);
     q += __shfl_xor(q, 32);
-    const float rstd = 1.0f / sqrtf(q * inv_n + eps);
+    const float mean = s * inv_n;
+    const float var = fmaxf(fmaf(-mean, mean, q * inv_n), 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float shift = -mean * rstd;
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
         const f32x4 w4 = *(const f32x4*)(lnw + T * 16 + g * 4);
         const f32x4 b4 = *(const f32x4*)(lnb + T * 16 + g * 4);
-        f32x4 v = (acc[T] - mean) * rstd * w4 + b4;
-        const int code = ACT >= 0 ? ACT : act;
-        v.x = act_apply(v.x, code);
-        v.y = act_apply(v.y, code);
-        v.z = act_apply(v.z, code);
-        v.w = act_apply(v.w, code);
+        f32x4 v;
+        v.x = act_b<ACT>(fmaf(fmaf(acc[T].x, rstd, shift), w4.x, b4.x), act);
+        v.y = act_b<ACT>(fmaf(fmaf(acc[T].y, rstd, shift), w4.y, b4.y), act);
+        v.z = act_b<ACT>(fmaf(fmaf(acc[T].z, rstd, shift), w4.z, b4.z), act);
+        v.w = act_b<ACT>(fmaf(fmaf(acc[T].w, rstd, shift), w4.w, b4.w), act);
         acc[T] = v;
     }
 }
