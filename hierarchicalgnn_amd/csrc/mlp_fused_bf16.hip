@@ -260,17 +260,30 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp_bf16(const MlpArgsBf16 
             WStage st = begin_stage_bytes(a.W[0], row_bytes, 0, lds, wave, lane);
             for (int i = 0; i < n_pieces; ++i) stage_next(st);
         }
+        // X stream: four chunks in flight.  A chunk's MFMAs take only ~512 cycles here (16x the fp32
+        // rate), far less than a global-load latency, so (i) the prefetch distance is 4 chunks and
+        // (ii) the new X load is issued AFTER this iteration's DMA pieces, which lets the drain before
+        // the barrier be `vmcnt(1)`: every DMA piece (older) has landed, the youngest X load stays in
+        // flight.  With `vmcnt(0)` each chunk waited out a full memory latency (5.2 ms -> see DESIGN).
         u16x8 x0 = next_x();
         u16x8 x1 = next_x();
+        u16x8 x2 = next_x();
+        u16x8 x3 = next_x();
+        bool x_in_flight = nc > 3;  // was an X load issued after the previous iteration's DMA pieces?
         for (int c = 0; c < nc; ++c) {
-            wait_dma();
+            if (x_in_flight)
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail: the youngest op IS a DMA piece
             __syncthreads();
-            const u16x8 x2 = next_x();
             const float* wb = lds + (c & 1) * BUF + lane * 4;
             WStage st = begin_stage_bytes(a.W[0], row_bytes, (size_t)(c + 1) * 64, lds + ((c + 1) & 1) * BUF, wave, lane);
             mma_chunk_b<NT1, NT1 * 16>(acc1, wb, x0, st, c + 1 < nc ? n_pieces : 0);
             x0 = x1;
             x1 = x2;
+            x2 = x3;
+            x_in_flight = cl < nc;  // next_x() below really loads (wave-uniform)
+            x3 = next_x();
         }
     }
     __builtin_amdgcn_s_setprio(0);
