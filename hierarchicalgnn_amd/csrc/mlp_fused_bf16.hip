@@ -107,16 +107,19 @@ __device__ __forceinline__ void layernorm_act_b(f32x4 (&acc)[NT], const float* _
     }
 }
 
-// one 32-wide k-chunk:  acc[T] += Wchunk[T] * b  for every 16-feature tile, A fragments pipelined one
-// pair ahead, the next chunk's LDS-DMA pieces issued between MFMA groups
-template <int NT, int NF_NEXT>
-__device__ __forceinline__ void mma_chunk_b(f32x4 (&acc)[NT], const float* __restrict__ wb, const u16x8 b,
-                                            WStage& st, int n_pieces) {
+// one 32-wide k-chunk:  acc[eg][T] += Wchunk[T] * b[eg]  for every 16-feature tile and each of the
+// wave's EG edge groups (one A fragment feeds EG MFMAs), A fragments pipelined one pair ahead, the
+// LDS-DMA pieces of a later chunk issued between MFMA groups
+template <int EG, int NT, int NF_NEXT>
+__device__ __forceinline__ void mma_chunk_b(f32x4 (&acc)[EG][NT], const float* __restrict__ wb,
+                                            const u16x8 (&b)[EG], WStage& st, int n_pieces) {
     static_assert(NT % 2 == 0, "tiles are processed in pairs");
     constexpr int PAIRS = NT / 2;
     constexpr int PER_WAVE = (NF_NEXT / 16 + 3) / 4;
     constexpr int EVERY = PAIRS >= PER_WAVE ? PAIRS / PER_WAVE : 1;
-    const bf16x8 bb = as_bf16(b);
+    bf16x8 bb[EG];
+#pragma unroll
+    for (int eg = 0; eg < EG; ++eg) bb[eg] = as_bf16(b[eg]);
     u16x8 w0 = *(const u16x8*)(wb);
     u16x8 w1 = *(const u16x8*)(wb + 256);
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -132,12 +135,15 @@ __device__ __forceinline__ void mma_chunk_b(f32x4 (&acc)[NT], const float* __res
             if (__builtin_amdgcn_readfirstlane(issued < n_pieces ? 1 : 0)) stage_next(st);
             ++issued;
         }
-        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(w0), bb, acc[T], 0, 0, 0);
-        acc[T + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(w1), bb, acc[T + 1], 0, 0, 0);
+#pragma unroll
+        for (int eg = 0; eg < EG; ++eg) {
+            acc[eg][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(w0), bb[eg], acc[eg][T], 0, 0, 0);
+            acc[eg][T + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(w1), bb[eg], acc[eg][T + 1], 0, 0, 0);
+        }
         w0 = n0;
         w1 = n1;
         if (T + 2 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * EG, 0);
     }
     for (int i = issued; i < n_pieces; ++i) stage_next(st);
 }
@@ -148,27 +154,49 @@ __device__ __forceinline__ void init_bias_b(f32x4 (&acc)[NT], const float* __res
     for (int T = 0; T < NT; ++T) acc[T] = *(const f32x4*)(b + T * 16 + g * 4);
 }
 
-// register-resident layer: `in` = packed k-blocks of the previous layer's activations
-template <int NKB, int NTO>
-__device__ __forceinline__ void dense_from_regs_b(const u16x8 (&in)[NKB], f32x4 (&out)[NTO],
+// s_waitcnt vmcnt(N) with a compile-time N (the asm immediate)
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// register-resident layer: `in[eg]` = packed k-blocks of the previous layer's activations.
+// NBUF-deep LDS ring: the pieces of chunk c+NBUF-1 are issued during chunk c, so a chunk's DMA has
+// NBUF-1 chunk times to land (one chunk of bf16 MFMAs is shorter than an L2 round trip).
+template <int EG, int NBUF, int NKB, int NTO>
+__device__ __forceinline__ void dense_from_regs_b(const u16x8 (&in)[EG][NKB], f32x4 (&out)[EG][NTO],
                                                   const unsigned short* __restrict__ W, float* lds, int wave,
                                                   int lane) {
     constexpr int KD = NKB * 32;          // input features
     constexpr int BUF = NTO * 256;        // floats (= 1 KiB pieces) per chunk buffer
+    constexpr int PIECES = NTO;           // 16-row pieces per chunk
+    constexpr bool EVEN = PIECES % 4 == 0;
+    constexpr int PW = PIECES / 4;        // pieces per wave when EVEN
     const int n_pieces = pieces_of<NTO * 16>(wave);
     const size_t row_bytes = (size_t)KD * 2;
     __syncthreads();
-    {
-        WStage st = begin_stage_bytes(W, row_bytes, 0, lds, wave, lane);
-        for (int i = 0; i < n_pieces; ++i) stage_next(st);
+#pragma unroll
+    for (int p = 0; p < NBUF - 1; ++p) {
+        if (p < NKB) {
+            WStage st = begin_stage_bytes(W, row_bytes, (size_t)p * 64, lds + p * BUF, wave, lane);
+            for (int i = 0; i < n_pieces; ++i) stage_next(st);
+        }
     }
 #pragma unroll
     for (int c = 0; c < NKB; ++c) {
-        wait_dma();
+        // chunk c must have landed; chunks c+1 .. c+NBUF-2 (younger) may stay in flight
+        constexpr int AHEAD = NBUF - 2;
+        if (EVEN && c + AHEAD < NKB) wait_vm<(EVEN ? AHEAD * PW : 0)>();
+        else wait_vm<0>();
         __syncthreads();
-        const float* wb = lds + (c & 1) * BUF + lane * 4;
-        WStage st = begin_stage_bytes(W, row_bytes, (size_t)(c + 1) * 64, lds + ((c + 1) & 1) * BUF, wave, lane);
-        mma_chunk_b<NTO, NTO * 16>(out, wb, in[c], st, c + 1 < NKB ? n_pieces : 0);
+        const float* wb = lds + (c % NBUF) * BUF + lane * 4;
+        const int cn = c + NBUF - 1;
+        WStage st = begin_stage_bytes(W, row_bytes, (size_t)cn * 64, lds + (cn % NBUF) * BUF, wave, lane);
+        u16x8 b[EG];
+#pragma unroll
+        for (int eg = 0; eg < EG; ++eg) b[eg] = in[eg][c];
+        mma_chunk_b<EG, NTO, NTO * 16>(out, wb, b, st, cn < NKB ? n_pieces : 0);
     }
 }
 
@@ -204,121 +232,153 @@ __device__ __forceinline__ void store_out_b(const f32x4 (&acc)[NT], const MlpArg
     }
 }
 
-template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O>
+// per-lane X stream of one edge: a running pointer that hops to the next segment's row
+struct XStream {
+    const unsigned short* q1;
+    const unsigned short* q2;
+    const unsigned short* px;
+};
+
+// EG: 16-edge groups per wave (1 or 2); NBUF: LDS weight-ring depth (2 or 3)
+template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, int EG, int NBUF>
 __global__ __launch_bounds__(256, MINW) void k_fused_mlp_bf16(const MlpArgsBf16 a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ei = lane & 15;
     const int g = lane >> 4;
-    const long long e = (long long)blockIdx.x * 64 + wave * 16 + ei;
-    const bool valid = e < a.M;
-    const long long er = valid ? e : 0;
-
-    // per-lane row start (+ 8g elements) of every input segment; one running pointer hops segments
-    const unsigned short* q0;
-    const unsigned short* q1;
-    const unsigned short* q2;
-    {
+    long long e[EG];
+    bool valid[EG];
+    XStream xs[EG];
+#pragma unroll
+    for (int eg = 0; eg < EG; ++eg) {
+        e[eg] = ((long long)blockIdx.x * 4 + wave) * (16 * EG) + eg * 16 + ei;
+        valid[eg] = e[eg] < a.M;
+        const long long er = valid[eg] ? e[eg] : 0;
         long long r = a.seg_index[0] != nullptr ? (long long)a.seg_index[0][er] : er;
-        q0 = a.seg_table[0] + (size_t)(r < 0 ? 0 : r) * (size_t)a.seg_width[0] + g * 8;
-        q1 = q0;
-        q2 = q0;
+        xs[eg].px = a.seg_table[0] + (size_t)(r < 0 ? 0 : r) * (size_t)a.seg_width[0] + g * 8;
+        xs[eg].q1 = xs[eg].px;
+        xs[eg].q2 = xs[eg].px;
         if (a.n_seg > 1) {
             r = a.seg_index[1] != nullptr ? (long long)a.seg_index[1][er] : er;
-            q1 = a.seg_table[1] + (size_t)(r < 0 ? 0 : r) * (size_t)a.seg_width[1] + g * 8;
+            xs[eg].q1 = a.seg_table[1] + (size_t)(r < 0 ? 0 : r) * (size_t)a.seg_width[1] + g * 8;
         }
         if (a.n_seg > 2) {
             r = a.seg_index[2] != nullptr ? (long long)a.seg_index[2][er] : er;
-            q2 = a.seg_table[2] + (size_t)(r < 0 ? 0 : r) * (size_t)a.seg_width[2] + g * 8;
+            xs[eg].q2 = a.seg_table[2] + (size_t)(r < 0 ? 0 : r) * (size_t)a.seg_width[2] + g * 8;
         }
     }
     const int nc = a.K1 / 32;
     const int c1 = a.seg_width[0] / 32;
     const int c2 = c1 + (a.n_seg > 1 ? a.seg_width[1] / 32 : nc);
-    const unsigned short* px = q0;
-    int cl = 0;
-    auto next_x = [&]() -> u16x8 {
-        u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (cl < nc) v = *(const u16x8*)px;
+    // The X operand also travels by LDS-DMA: every wave gathers its own B fragments (per-lane source
+    // row, lane*16-byte destination = B-fragment order) into a private 4-slot ring and reads them back
+    // with ds_read_b128.  Reason: with X in ordinary global loads hipcc guards their first use with
+    // `s_waitcnt vmcnt(k)`, k counting only ITS loads; the hand-issued weight DMAs sit in the same
+    // in-order queue, so that wait drained the weight ring every chunk (59 % of wave time parked).
+    // With every VMEM op of the loop issued by hand, the counted drains below are the only waits.
+    constexpr int MAXNT = NT1 > NT2 ? (NT1 > NT3 ? NT1 : NT3) : (NT2 > NT3 ? NT2 : NT3);
+    float* xring = lds + NBUF * MAXNT * 256 + wave * (4 * EG * 256);
+    int cl = 0;  // next chunk the X streams will fetch (the same for every edge group)
+    auto issue_x = [&]() {
+#pragma unroll
+        for (int eg = 0; eg < EG; ++eg) {
+            if (cl < nc) dma_piece((const char*)xs[eg].px, lds_addr_of(xring + ((cl & 3) * EG + eg) * 256));
+            xs[eg].px += 32;
+            if (cl + 1 == c1) xs[eg].px = xs[eg].q1;
+            if (cl + 1 == c2) xs[eg].px = xs[eg].q2;
+        }
         ++cl;
-        px += 32;
-        if (cl == c1) px = q1;
-        if (cl == c2) px = q2;
-        return v;
     };
 
     // ---------------- layer 1
-    f32x4 acc1[NT1];
-    init_bias_b<NT1>(acc1, a.b[0], g);
+    f32x4 acc1[EG][NT1];
+#pragma unroll
+    for (int eg = 0; eg < EG; ++eg) init_bias_b<NT1>(acc1[eg], a.b[0], g);
     __builtin_amdgcn_s_setprio(2);
     {
         constexpr int BUF = NT1 * 256;
+        constexpr bool EVEN = NT1 % 4 == 0;
+        constexpr int PW = NT1 / 4;
         const int n_pieces = pieces_of<NT1 * 16>(wave);
         const size_t row_bytes = (size_t)a.K1 * 2;
-        {
-            WStage st = begin_stage_bytes(a.W[0], row_bytes, 0, lds, wave, lane);
-            for (int i = 0; i < n_pieces; ++i) stage_next(st);
+        // prologue = the "virtual iterations" -3, -2, -1 in the SAME issue order as the steady state
+        // (weights of chunk i+NBUF-1, then X of chunk i+3), so that the counted drain holds from c = 0
+#pragma unroll
+        for (int i = -3; i < 0; ++i) {
+            const int cw = i + NBUF - 1;
+            if (cw >= 0 && cw < nc) {
+                WStage st = begin_stage_bytes(a.W[0], row_bytes, (size_t)cw * 64, lds + (cw % NBUF) * BUF, wave, lane);
+                for (int k = 0; k < n_pieces; ++k) stage_next(st);
+            }
+            issue_x();
         }
-        // X stream: four chunks in flight.  A chunk's MFMAs take only ~512 cycles here (16x the fp32
-        // rate), far less than a global-load latency, so (i) the prefetch distance is 4 chunks and
-        // (ii) the new X load is issued AFTER this iteration's DMA pieces, which lets the drain before
-        // the barrier be `vmcnt(1)`: every DMA piece (older) has landed, the youngest X load stays in
-        // flight.  With `vmcnt(0)` each chunk waited out a full memory latency (5.2 ms -> see DESIGN).
-        u16x8 x0 = next_x();
-        u16x8 x1 = next_x();
-        u16x8 x2 = next_x();
-        u16x8 x3 = next_x();
-        bool x_in_flight = nc > 3;  // was an X load issued after the previous iteration's DMA pieces?
+        // Queue order per iteration: [weight pieces of chunk c+NBUF-1] then [EG X pieces of chunk c+3].
+        // When iteration c begins, the ops YOUNGER than the data it needs (weights of chunk c, issued in
+        // iteration c-NBUF+1; X of chunk c, older still) are (NBUF-2) later chunks of weight pieces and
+        // (NBUF-1) iterations' X pieces: that many may stay in flight.  The last iterations issue fewer ops and drain completely.
         for (int c = 0; c < nc; ++c) {
-            if (x_in_flight)
-                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail: the youngest op IS a DMA piece
+            if (EVEN && c + NBUF + 2 < nc) wait_vm<(EVEN ? (NBUF - 2) * PW + (NBUF - 1) * EG : 0)>();
+            else wait_vm<0>();
             __syncthreads();
-            const float* wb = lds + (c & 1) * BUF + lane * 4;
-            WStage st = begin_stage_bytes(a.W[0], row_bytes, (size_t)(c + 1) * 64, lds + ((c + 1) & 1) * BUF, wave, lane);
-            mma_chunk_b<NT1, NT1 * 16>(acc1, wb, x0, st, c + 1 < nc ? n_pieces : 0);
-            x0 = x1;
-            x1 = x2;
-            x2 = x3;
-            x_in_flight = cl < nc;  // next_x() below really loads (wave-uniform)
-            x3 = next_x();
+            const float* wb = lds + (c % NBUF) * BUF + lane * 4;
+            const int cn = c + NBUF - 1;
+            WStage st = begin_stage_bytes(a.W[0], row_bytes, (size_t)cn * 64, lds + (cn % NBUF) * BUF, wave, lane);
+            u16x8 x0[EG];
+#pragma unroll
+            for (int eg = 0; eg < EG; ++eg) x0[eg] = *(const u16x8*)(xring + ((c & 3) * EG + eg) * 256 + lane * 4);
+            mma_chunk_b<EG, NT1, NT1 * 16>(acc1, wb, x0, st, cn < nc ? n_pieces : 0);
+            issue_x();  // chunk c+3 into the slot chunk c-1 was read from
         }
     }
     __builtin_amdgcn_s_setprio(0);
-    layernorm_act_b<NT1, ACT_H>(acc1, a.lnw[0], a.lnb[0], a.act[0], a.eps, g);
-    u16x8 h1[NT1 / 2];
-    pack_all<NT1>(acc1, h1);
+    u16x8 h1[EG][NT1 / 2];
+#pragma unroll
+    for (int eg = 0; eg < EG; ++eg) {
+        layernorm_act_b<NT1, ACT_H>(acc1[eg], a.lnw[0], a.lnb[0], a.act[0], a.eps, g);
+        pack_all<NT1>(acc1[eg], h1[eg]);
+    }
 
     // ---------------- layer 2 (and 3)
-    f32x4 acc2[NT2];
-    init_bias_b<NT2>(acc2, a.b[1], g);
+    f32x4 acc2[EG][NT2];
+#pragma unroll
+    for (int eg = 0; eg < EG; ++eg) init_bias_b<NT2>(acc2[eg], a.b[1], g);
     __builtin_amdgcn_s_setprio(2);
-    dense_from_regs_b<NT1 / 2, NT2>(h1, acc2, a.W[1], lds, wave, lane);
+    dense_from_regs_b<EG, NBUF, NT1 / 2, NT2>(h1, acc2, a.W[1], lds, wave, lane);
     __builtin_amdgcn_s_setprio(0);
-    layernorm_act_b<NT2, (NT3 == 0 ? ACT_O : ACT_H)>(acc2, a.lnw[1], a.lnb[1], a.act[1], a.eps, g);
     if constexpr (NT3 == 0) {
-        store_out_b<NT2>(acc2, a, e, valid, g);
+#pragma unroll
+        for (int eg = 0; eg < EG; ++eg) {
+            layernorm_act_b<NT2, ACT_O>(acc2[eg], a.lnw[1], a.lnb[1], a.act[1], a.eps, g);
+            store_out_b<NT2>(acc2[eg], a, e[eg], valid[eg], g);
+        }
     } else {
-        u16x8 h2[NT2 / 2];
-        pack_all<NT2>(acc2, h2);
-        f32x4 acc3[NT3];
-        init_bias_b<NT3>(acc3, a.b[2], g);
+        u16x8 h2[EG][NT2 / 2];
+#pragma unroll
+        for (int eg = 0; eg < EG; ++eg) {
+            layernorm_act_b<NT2, ACT_H>(acc2[eg], a.lnw[1], a.lnb[1], a.act[1], a.eps, g);
+            pack_all<NT2>(acc2[eg], h2[eg]);
+        }
+        f32x4 acc3[EG][NT3];
+#pragma unroll
+        for (int eg = 0; eg < EG; ++eg) init_bias_b<NT3>(acc3[eg], a.b[2], g);
         __builtin_amdgcn_s_setprio(2);
-        dense_from_regs_b<NT2 / 2, NT3>(h2, acc3, a.W[2], lds, wave, lane);
+        dense_from_regs_b<EG, NBUF, NT2 / 2, NT3>(h2, acc3, a.W[2], lds, wave, lane);
         __builtin_amdgcn_s_setprio(0);
-        layernorm_act_b<NT3, ACT_O>(acc3, a.lnw[2], a.lnb[2], a.act[2], a.eps, g);
-        store_out_b<NT3>(acc3, a, e, valid, g);
+#pragma unroll
+        for (int eg = 0; eg < EG; ++eg) {
+            layernorm_act_b<NT3, ACT_O>(acc3[eg], a.lnw[2], a.lnb[2], a.act[2], a.eps, g);
+            store_out_b<NT3>(acc3[eg], a, e[eg], valid[eg], g);
+        }
     }
 }
 
-template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O>
+template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, int EG, int NBUF>
 static int launch_b_act(const MlpArgsBf16& a, hipStream_t s) {
     constexpr int maxnt = NT1 > NT2 ? (NT1 > NT3 ? NT1 : NT3) : (NT2 > NT3 ? NT2 : NT3);
-    const size_t lds_bytes = (size_t)2 * maxnt * 256 * sizeof(float);
-    const unsigned grid = (unsigned)ceil_div(a.M, 64);
-    auto kern = k_fused_mlp_bf16<NT1, NT2, NT3, MINW, ACT_H, ACT_O>;
+    const size_t lds_bytes = ((size_t)NBUF * maxnt + 4 * 4 * EG) * 256 * sizeof(float);  // weight ring + X rings
+    const unsigned grid = (unsigned)ceil_div(a.M, 64 * EG);
+    auto kern = k_fused_mlp_bf16<NT1, NT2, NT3, MINW, ACT_H, ACT_O, EG, NBUF>;
     if (lds_bytes > 64 * 1024) {
         HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
@@ -328,15 +388,27 @@ static int launch_b_act(const MlpArgsBf16& a, hipStream_t s) {
     return HGNN_OK;
 }
 
-template <int NT1, int NT2, int NT3, int MINW>
-static int launch_b(const MlpArgsBf16& a, hipStream_t s) {
+int g_opt_mlp_bf16_shape = 1;  // hgnn_set_option("mlp_bf16_shape"): 0 = 16 edges/wave, 2-deep ring; 1 = 32 edges/wave, 3-deep ring
+
+template <int NT1, int NT2, int NT3, int MINW, int EG, int NBUF>
+static int launch_b_shape(const MlpArgsBf16& a, hipStream_t s) {
     const int n = NT3 == 0 ? 2 : 3;
     bool hidden_gelu = true;
     for (int l = 0; l + 1 < n; ++l) hidden_gelu = hidden_gelu && a.act[l] == HGNN_ACT_GELU;
     const int out = a.act[n - 1];
-    if (hidden_gelu && out == HGNN_ACT_TANH) return launch_b_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_TANH>(a, s);
-    if (hidden_gelu && out == HGNN_ACT_GELU) return launch_b_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_GELU>(a, s);
-    return launch_b_act<NT1, NT2, NT3, MINW, -1, -1>(a, s);
+    if (hidden_gelu && out == HGNN_ACT_TANH) return launch_b_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_TANH, EG, NBUF>(a, s);
+    if (hidden_gelu && out == HGNN_ACT_GELU) return launch_b_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_GELU, EG, NBUF>(a, s);
+    return launch_b_act<NT1, NT2, NT3, MINW, -1, -1, EG, NBUF>(a, s);
+}
+
+template <int NT1, int NT2, int NT3, int MINW>
+static int launch_b(const MlpArgsBf16& a, hipStream_t s) {
+    // wide layers: 32 edges per wave (one weight fragment feeds two MFMAs), one workgroup per CU,
+    // 3-deep weight ring; narrow layers keep 16 edges per wave at higher occupancy
+    if constexpr (NT1 >= 16) {
+        if (g_opt_mlp_bf16_shape == 1) return launch_b_shape<NT1, NT2, NT3, 1, 2, 3>(a, s);
+    }
+    return launch_b_shape<NT1, NT2, NT3, MINW, 1, 2>(a, s);
 }
 
 }  // namespace hgnn

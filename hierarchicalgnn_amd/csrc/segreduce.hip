@@ -24,6 +24,7 @@ namespace hgnn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern int g_opt_mlp_ablate;
+extern int g_opt_mlp_bf16_shape;
 
 static int g_opt_nt_loads = 1;   // non-temporal loads for once-read source rows
 static int g_opt_nt_stores = 0;  // non-temporal stores for gather output
@@ -492,6 +493,7 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     else if (!strcmp(name, "seg_wpb")) g_opt_seg_wpb = value;
     else if (!strcmp(name, "seg_xcd")) g_opt_seg_xcd = value;
     else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 7;
+    else if (!strcmp(name, "mlp_bf16_shape")) g_opt_mlp_bf16_shape = value;
     else {
         set_error("hgnn_set_option: unknown option '%s'", name);
         return HGNN_ERR_INVALID_ARG;

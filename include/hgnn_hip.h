@@ -103,6 +103,8 @@ int hgnn_sizeof_mlp_desc(void);
 
 /* Process-wide switches for A/B measurements:
  *   "nt_loads", "nt_stores", "seg_unroll", "seg_wpb", "seg_xcd"   K1..K6 launch shape / cache policy
+ *   "mlp_bf16_shape" bf16 MLP launch shape: 0 = 16 edges/wave, 2-deep weight ring; 1 (default) = 32
+ *                  edges/wave, 3-deep ring for wide layers
  *   "mlp_ablate"   DIAGNOSTIC bits, results are WRONG: 1 skip LayerNorm/act, 2 skip weight DMA,
  *                  4 skip barriers (used to price those parts; tools/tune_mlp.py) */
 int hgnn_set_option(const char* name, int value);

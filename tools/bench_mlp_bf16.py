@@ -46,6 +46,12 @@ with torch.no_grad():
     seg16 = [(nodes16, graph[0]), (nodes16, graph[1]), (edges16, None)]
     t = timeit(lambda: mlp.concat_mlp(net, seg32, skip=edges32))
     res["fp32_fused_ms"], res["fp32_fused_tflops"] = t, flop / t / 1e9
+    from hierarchicalgnn_amd import _lib
+    lib = _lib.load()
+    lib.hgnn_set_option(b"mlp_bf16_shape", 0)
+    t = timeit(lambda: mlp.concat_mlp(net, seg16, skip=edges16))
+    res["bf16_fused_16edges_2ring_ms"] = t
+    lib.hgnn_set_option(b"mlp_bf16_shape", 1)
     a = mlp.concat_mlp(net, seg16, skip=edges16)
     t = timeit(lambda: mlp.concat_mlp(net, seg16, skip=edges16))
     res["bf16_fused_ms"], res["bf16_fused_tflops"] = t, flop / t / 1e9
