@@ -22,9 +22,14 @@
 //     buffered, one barrier per chunk); the activations X are read straight from
 //     global memory into the B-operand layout (16 rows x 64 B per wave load),
 //     with the row gather folded into the per-lane address.
-//   * 2 workgroups per CU (<=256 VGPRs) so that one block's LayerNorm/GELU
-//     epilogue (VALU) overlaps the other's MFMAs; the 3-layer L=256 node
-//     network needs 320 accumulator registers and runs at 1 workgroup per CU.
+//   * 2 workgroups per CU (<=256 VGPRs); the 3-layer L=256 node network needs 320
+//     accumulator registers and runs at 1 workgroup per CU.  NOTE: the fp32 MFMA
+//     executes on the SIMD's fp32 vector ALUs, so epilogue VALU work does NOT hide
+//     under a co-resident wave's MFMAs (measured): the epilogue is kept
+//     short (branch-free erf/tanh) rather than overlapped.
+//   * small-K mode (encoders, K = 3 / 6) and width-1 plain last layers (heads) are
+//     handled by zero padding (see hgnn_mlp_desc in include/hgnn_hip.h); `save_pre`
+//     dumps the pre-LayerNorm outputs for the opt-in differentiable variant.
 #include "mlp_common.h"
 
 namespace hgnn {

@@ -1,12 +1,14 @@
-"""Fused gather -> concat -> [Linear -> LayerNorm -> act] x {2,3} -> (+skip) on fp32 MFMA
-(``hgnn_mlp_forward_f32``, csrc/mlp_fused.hip).
+"""Fused gather -> concat -> [Linear -> LayerNorm -> act] x {2,3} -> (+skip) on MFMA:
+``hgnn_mlp_forward_f32`` (csrc/mlp_fused.hip, fp32 rows) and ``hgnn_mlp_forward_bf16``
+(csrc/mlp_fused_bf16.hip, bf16 rows).  Covers the cell networks, the encoders (small-K mode)
+and the width-1 classifier heads.
 
 ``supported`` decides per call; when it says no, ``concat_mlp`` evaluates the same
 Sequential with HIP row gathers + library GEMMs (still on the GPU).  The fused kernel is
-forward-only, so it is used whenever autograd is not recording: inference, and the first
-(no-grad) pass of every reentrant ``torch.utils.checkpoint`` segment -- which is how the
-reference runs all of its updates (Modules/gnn_utils.py:14-15).  The recompute pass inside
-backward needs saved activations and takes the differentiable path.
+used whenever autograd is not recording: inference, and the first (no-grad) pass of every
+reentrant ``torch.utils.checkpoint`` segment -- which is how the reference runs all of its
+updates (Modules/gnn_utils.py:14-15).  When autograd records, the library path is taken;
+a differentiable variant of the fused kernel exists but is opt-in (see ``_train_enabled``).
 """
 from __future__ import annotations
 
