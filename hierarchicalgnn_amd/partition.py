@@ -304,3 +304,86 @@ def distributed_hgnn_cell_forward(cell, halo: HaloExchange, nodes_owned, edges_l
     nodes_ext = halo.extend(nodes_owned)
     edges_local = cell.edge_update(nodes_ext, edges_local, local_graph)
     return nodes_owned, edges_local, supernodes, superedges
+
+
+# --------------------------------------------------------------------------- whole EC-IN model on shards
+@dataclass
+class EdgePairExchange:
+    """The EC head pairs the latent of stored edge k (u -> v, owned by owner(v)) with the latent of its
+    reverse E+k (v -> u, owned by owner(u)) (EdgeClassifier/Models/IN.py:126).  For cut edges the two
+    halves live on different ranks: one ragged all-to-all per forward ships every reverse half to the
+    owner of its forward half."""
+    fwd_local: torch.Tensor      # [F_p] local indices of my forward edges (global directed id < E)
+    fwd_global: torch.Tensor     # [F_p] their stored-edge ids k
+    partner_local: torch.Tensor  # [F_p] local index of the reverse half, or -1 if it arrives by exchange
+    partner_recv: torch.Tensor   # [F_p] row in the receive buffer, or -1 if local
+    send_index: torch.Tensor     # local indices of the reverse halves I must send, grouped by destination
+    send_splits: List[int] = field(default_factory=list)
+    recv_splits: List[int] = field(default_factory=list)
+
+
+def edge_pair_exchange(x, edge_index, world: int, rank: int, shard: EventShard) -> EdgePairExchange:
+    E = int(edge_index.shape[1])
+    graph = torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    owner, _ = node_owner(x, graph, world)
+    edge_owner = owner[graph[1]]                      # owner of every directed edge
+    g2l = torch.full((2 * E,), -1, dtype=torch.long)
+    g2l[shard.edge_global] = torch.arange(shard.edge_global.numel())
+    k = torch.arange(E)
+    mine_fwd = edge_owner[:E] == rank
+    fwd_global = k[mine_fwd]
+    fwd_local = g2l[fwd_global]
+    partner_owner = edge_owner[E:][mine_fwd]
+    partner_local = torch.where(partner_owner == rank, g2l[fwd_global + E], torch.full_like(fwd_global, -1))
+    partner_recv = torch.full_like(fwd_global, -1)
+    recv_splits, off = [], 0
+    for a in range(world):
+        sel = partner_owner == a
+        n = int(sel.sum()) if a != rank else 0
+        if a != rank:
+            partner_recv[sel] = off + torch.arange(n)  # sender a sends in increasing k order
+        recv_splits.append(n)
+        off += n
+    send_splits, parts = [], []
+    for q in range(world):
+        if q == rank:
+            send_splits.append(0)
+            continue
+        sel = (edge_owner[E:] == rank) & (edge_owner[:E] == q)   # my reverse halves whose forward half is on q
+        parts.append(g2l[k[sel] + E])
+        send_splits.append(int(sel.sum()))
+    send_index = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.long)
+    return EdgePairExchange(fwd_local, fwd_global, partner_local, partner_recv, send_index.contiguous(),
+                            send_splits, recv_splits)
+
+
+def distributed_ec_forward(node_encode, edge_encode, cells, head, shard: EventShard, halo: HaloExchange,
+                           pairs: EdgePairExchange, x_owned: torch.Tensor, group=None):
+    """EC_InteractionGNN.forward (EdgeClassifier/Models/IN.py:80-128) on one shard of a node-partitioned
+    event.  ``node_encode(x)``, ``edge_encode(x_ext, graph)``, ``cells`` (objects with node_update /
+    edge_update) and ``head(pair_rows)`` are the model's own pieces.  Collectives: one halo exchange of
+    the 3 input coordinates, one per cell (latent rows), one edge-pair exchange before the head.
+    Returns (scores of my forward edges, their stored-edge ids)."""
+    dev = x_owned.device
+    graph = shard.local_graph.to(dev)
+    x_ext = halo.extend(x_owned)
+    nodes = node_encode(x_owned)
+    edges = edge_encode(x_ext, graph)
+    for cell in cells:
+        nodes, edges = distributed_cell_forward(cell, halo, nodes, edges, graph)
+    recv = _A2A.apply(_pack(edges, pairs.send_index.to(dev)), pairs.send_splits, pairs.recv_splits, group)
+    both = torch.cat([edges, recv], dim=0)
+    partner = torch.where(pairs.partner_local >= 0, pairs.partner_local,
+                          edges.shape[0] + pairs.partner_recv).to(dev)
+    rows = torch.cat([_pack(edges, pairs.fwd_local.to(dev)), _pack(both, partner)], dim=1)
+    return torch.sigmoid(head(rows).squeeze(-1)), pairs.fwd_global
+
+
+def distributed_ec_forward_model(model, shard: EventShard, halo: HaloExchange, pairs: EdgePairExchange,
+                                 x_owned: torch.Tensor, group=None):
+    """``distributed_ec_forward`` with the pieces of a ``hierarchicalgnn_amd.models.EC_InteractionGNN``"""
+    from .mlp import concat_mlp
+    blk = model.ignn_block
+    return distributed_ec_forward(blk._encode_nodes, blk._encode_edges, list(blk.ignn_cells),
+                                  lambda rows: concat_mlp(model.edge_classifier, [(rows, None)]),
+                                  shard, halo, pairs, x_owned, group)

@@ -1,0 +1,63 @@
+"""The multi-GPU code path on ONE MI355X with a real RCCL communicator (world_size 1): the
+collectives, streams and HIP pack/unpack kernels of partition.py run exactly as they do per rank
+at N > 1; the result must equal the plain single-GPU model.  (Multi-rank correctness is covered by
+the gloo tests; the 8-GPU run is the driver's.)"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rccl_world1():
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["all_gather", "all_to_all"])
+def test_distributed_ec_forward_on_rccl_world1(rccl_world1, mode):
+    from hierarchicalgnn_amd import partition, synth
+    from hierarchicalgnn_amd.models import EC_InteractionGNN
+    torch.manual_seed(0)
+    hp = dict(spatial_channels=3, latent=32, hidden=64, n_interaction_graph_iters=2, nb_node_layer=3,
+              nb_edge_layer=2, output_layers=3, hidden_output_activation="GELU", hidden_activation="GELU",
+              layernorm=True, share_weight=False)
+    model = EC_InteractionGNN(hp).cuda().eval()
+    x, ei = synth.trackml_event(3000, 20000, seed=5)
+    shard = partition.partition_event(x, ei, 1, 0)
+    halo = partition.HaloExchange(shard, "cuda", mode=mode)
+    pairs = partition.edge_pair_exchange(x, ei, 1, 0, shard)
+    with torch.no_grad():
+        ref = model(x.cuda(), ei.cuda())
+        scores, ids = partition.distributed_ec_forward_model(model, shard, halo, pairs, x[shard.owned_global].cuda())
+    assert scores.shape == (ei.shape[1],)
+    out = torch.empty_like(ref)
+    out[ids.cuda()] = scores
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_bench_step_shape_on_rccl_world1(rccl_world1):
+    """what bench.py does per step at N > 1: local K1 + halo exchange on a side stream"""
+    import hierarchicalgnn_amd as H
+    from hierarchicalgnn_amd import partition, synth
+    x, ei = synth.trackml_event(5000, 40000, seed=6)
+    shard = partition.partition_event(x, ei, 1, 0)
+    halo = partition.HaloExchange(shard, "cuda", mode="all_gather")
+    graph = shard.local_graph.cuda()
+    edges = torch.randn(graph.shape[1], 64, device="cuda")
+    nodes = torch.randn(shard.n_owned, 64, device="cuda")
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            h = halo.exchange(nodes)
+        out = H.scatter_add(edges, graph[1], dim=0, dim_size=shard.n_owned)
+        torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert h.shape == (shard.n_halo, 64) and out.shape == (shard.n_owned, 64)

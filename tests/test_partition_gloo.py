@@ -236,3 +236,73 @@ def test_partitioned_hierarchical_cell_matches_single_process():
         g_se += gse
     assert torch.allclose(g_sn, ref_in["sn"].grad, rtol=1e-4, atol=1e-5)    # replicated inputs: grads sum over ranks
     assert torch.allclose(g_se, ref_in["se"].grad, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------- whole EC-IN model on shards
+EC_HP = dict(spatial_channels=3, latent=16, hidden=32, n_interaction_graph_iters=3, nb_node_layer=3,
+             nb_edge_layer=2, output_layers=3, hidden_output_activation="GELU", hidden_activation="GELU",
+             layernorm=True, share_weight=False)
+
+
+def _make_ec_problem():
+    from hierarchicalgnn_amd.models import EC_InteractionGNN
+    torch.manual_seed(3)
+    model = EC_InteractionGNN(EC_HP)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x, ei = synth.trackml_event(500, 2500, seed=9)
+    return x, ei, sd
+
+
+class _OracleIGCell:
+    def __init__(self, sd, i):
+        self.sd, self.pfx = sd, f"ignn_block.ignn_cells.{i}."
+
+    def node_update(self, nodes, edges, graph):
+        return O.ignn_node_update(self.sd, self.pfx, EC_HP, nodes, edges, graph)
+
+    def edge_update(self, nodes, edges, graph):
+        return O.edge_update(self.sd, self.pfx, EC_HP, nodes, edges, graph)
+
+
+def _ec_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        x, ei, sd = _make_ec_problem()
+        shard = partition.partition_event(x, ei, world, rank)
+        halo = partition.HaloExchange(shard, "cpu", mode="all_to_all")
+        pairs = partition.edge_pair_exchange(x, ei, world, rank, shard)
+        node_encode = lambda t: O.mlp_apply(sd, "ignn_block.node_encoder.", t, 3, "GELU", "GELU", True)
+        edge_encode = lambda xe, g: O.mlp_apply(sd, "ignn_block.edge_encoder.", torch.cat([xe[g[0]], xe[g[1]]], 1),
+                                                2, "GELU", "GELU", True)
+        head = lambda rows: O.mlp_apply(sd, "edge_classifier.", rows, 3, "GELU", None, True)
+        cells = [_OracleIGCell(sd, i) for i in range(EC_HP["n_interaction_graph_iters"])]
+        with torch.no_grad():
+            scores, ids = partition.distributed_ec_forward(node_encode, edge_encode, cells, head, shard, halo, pairs,
+                                                           x[shard.owned_global])
+        q.put((rank, ids, scores))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partitioned_ec_model_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ec_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, ei, sd = _make_ec_problem()
+    ref = O.ec_in_forward(sd, EC_HP, x, ei)
+    seen = torch.zeros(ei.shape[1], dtype=torch.long)
+    for rank, ids, scores in results:
+        seen[ids] += 1
+        assert torch.allclose(scores, ref[ids], rtol=1e-5, atol=1e-6)
+    assert int(seen.min()) == 1 and int(seen.max()) == 1          # every stored edge scored exactly once
