@@ -131,10 +131,17 @@ def main():
     edges = torch.randn(M, L, device=device, generator=gen)
     nodes = torch.randn(n_local, L, device=device, generator=gen) if halo is not None else None
 
-    t0 = time.perf_counter()
-    plan = H.get_plan(graph[1], n_local)
+    plan = H.get_plan(graph[1], n_local)          # first build also loads the code object
     torch.cuda.synchronize()
-    plan_ms = (time.perf_counter() - t0) * 1e3
+    builds = []
+    for _ in range(3):                             # warm per-event cost: sort + CSR + work list, host wall, synced
+        idx_copy = graph[1].clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        H.GraphPlan(idx_copy, n_local)
+        torch.cuda.synchronize()
+        builds.append((time.perf_counter() - t0) * 1e3)
+    plan_ms = sorted(builds)[1]
     side = torch.cuda.Stream(device) if halo is not None else None
 
     def step():
