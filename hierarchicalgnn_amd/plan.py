@@ -149,6 +149,7 @@ def get_plan(dst_index: torch.Tensor, dim_size: int, gather_index: Optional[torc
 def clear_plan_cache():
     _CACHE.clear()
     _IDX_CACHE.clear()
+    _MEMO.clear()
 
 
 def plan_cache_stats():
@@ -189,4 +190,25 @@ def get_index32(index: torch.Tensor, limit: int) -> torch.Tensor:
     _IDX_CACHE[key] = (out, index)
     while len(_IDX_CACHE) > _CACHE_SIZE:
         _IDX_CACHE.popitem(last=False)
+    return out
+
+
+# --------------------------------------------------------------------------- derived index tensors
+_MEMO: "OrderedDict[tuple, tuple]" = OrderedDict()
+
+
+def memo(index: torch.Tensor, tag: str, make):
+    """``make()`` once per (index tensor identity/version, tag): per-event index tensors derived from
+    the caller's graph (the directed graph, its destination-sorted copy, the inverse permutation).
+    Handing back the SAME derived tensors on every call is what lets their plans hit the cache above
+    -- and what makes a whole forward capturable into a HIP graph (no sort, no plan build on replay)."""
+    key = (_key(index), tag)
+    hit = _MEMO.get(key)
+    if hit is not None:
+        _MEMO.move_to_end(key)
+        return hit[0]
+    out = make()
+    _MEMO[key] = (out, index)
+    while len(_MEMO) > 4 * _CACHE_SIZE:
+        _MEMO.popitem(last=False)
     return out

@@ -189,3 +189,22 @@ def test_hierarchy_from_clusters_matches_oracle_pieces():
     w_ref, _ = O.graph_edge_weights(means_ref, means_ref, sg.cpu(), one, zero, zero, one, "sigmoid", True)
     assert rel_err(sw.cpu().numpy(), w_ref.numpy()) <= TOL
     assert torch.equal(sg.cpu(), torch.unique(torch.cat([sg.cpu(), sg.cpu().flip(0)], 1), dim=1))  # symmetric
+
+
+def test_graphed_inference_replays_the_small_event_forward():
+    """BASELINE config 1 shape (2k hits / 12k edges, latent 32): captured HIP graph == eager forward"""
+    from hierarchicalgnn_amd.models import EC_InteractionGNN, GraphedInference
+    z = load_golden("ec_in_L32.npz")
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    model = _load(EC_InteractionGNN(hp), z).eval()
+    x = torch.from_numpy(z["x"]).cuda()
+    graph = torch.from_numpy(z["edge_index"]).cuda()
+    g = GraphedInference(model, x, graph)
+    s1 = g().clone()
+    assert np.abs(s1.cpu().numpy() - z["scores"]).max() <= 1e-4
+    x2 = x + 0.01 * torch.randn_like(x)
+    s2 = g(x2).clone()
+    with torch.no_grad():
+        ref2 = model(x2, graph)
+    assert torch.allclose(s2, ref2, rtol=1e-5, atol=1e-6)
+    assert not torch.allclose(s1, s2)
