@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class HgnnPlan(Structure):
@@ -76,6 +76,8 @@ _SIGNATURES = {
     "hgnn_mlp_forward_f32": (c_int, [POINTER(HgnnMlpDesc), c_void_p, c_void_p]),
     "hgnn_mlp_supported_bf16": (c_int, [POINTER(HgnnMlpDesc)]),
     "hgnn_mlp_forward_bf16": (c_int, [POINTER(HgnnMlpDesc), c_void_p, c_void_p]),
+    "hgnn_mlp_supported_bf16_split": (c_int, [POINTER(HgnnMlpDesc)]),
+    "hgnn_mlp_forward_bf16_split": (c_int, [POINTER(HgnnMlpDesc), c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,470 @@
+// bf16 fused  gather -> concat -> [Linear -> LayerNorm -> act] x {2,3} -> (+skip)  MLP, feature-split
+// decomposition (the wide-layer kernel: L in {128, 256, 512}; BASELINE config 4 is L = 512).
+//
+// mlp_fused_bf16.hip gives every wave 16-32 edges and ALL features, so each wave re-reads the whole
+// weight chunk from LDS: at 16x the fp32 matrix rate that LDS stream (and the DMA issue feeding it)
+// is what bounds it, and L = 512 does not fit a wave's accumulator registers at all.  Here a
+// workgroup owns TE = 64 edges and wave w owns a QUARTER OF THE FEATURES of every layer:
+//   * weights are private to a wave -> no LDS, no DMA: the host stores W in MFMA A-fragment order
+//     (fragment (k-chunk c, 16-feature tile T) = 1 KiB, lane l = W[16T + l%16][32c + 8(l/16) .. +7]),
+//     a wave streams its slice with plain 16-byte/lane global loads (always L2 hits: every
+//     workgroup reads the same ~1 MB) through a register ring that runs >= 8 fragments ahead;
+//   * one weight fragment feeds 4 MFMAs (the 4 edge tiles), a workgroup reads each weight byte once
+//     for 64 edges;
+//   * activations are what the waves share, so THEY go through LDS: the gathered input rows in
+//     128-wide k-panels (coalesced 256-byte row pieces, double-buffered), and the hidden activations of each
+//     layer as bf16 [64][H] (padded rows: conflict-free ds_write_b64 / ds_read_b128);
+//   * LayerNorm statistics: in-register partial sums over the wave's features, exchanged through
+//     LDS (2 floats per edge per wave), one-pass variance in fp32.
+// GEMMs are transposed as in the other kernels (A = W fragment, B = activations, D[f][e]): lane
+// (e = lane&15, g = lane>>4) holds features 16T + 4g + r of edge 16j + e.
+#include "mlp_common.h"
+
+namespace hgnn {
+namespace fs {
+
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TE = 64;  // edges per workgroup (4 MFMA column tiles)
+
+struct Args {
+    const unsigned short* seg_table[3];
+    const int32_t* seg_index[3];
+    int seg_width[3];
+    int n_seg;
+    int K1;
+    const unsigned short* W[3];  // bf16, A-fragment order (see header)
+    const float* b[3];
+    const float* lnw[3];
+    const float* lnb[3];
+    int act[3];
+    float eps;
+    const unsigned short* skip;
+    unsigned short* out;
+    long long M;
+};
+
+__device__ __forceinline__ bf16x8 as_bf16(u16x8 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf16_float(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+// GELU in its tanh form folded to x * sigmoid(2u) (same as mlp_fused_bf16.hip: |error| vs the erf
+// form <= 5e-4 absolute, below one bf16 ulp of the result)
+__device__ __forceinline__ float gelu_t(float x) {
+    const float t = x * fmaf(-0.10294324f, x * x, -2.30220820f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_t(float x, int act) {
+    const int code = ACT >= 0 ? ACT : act;
+    if (code == HGNN_ACT_GELU) return gelu_t(x);
+    return act_apply(x, code);
+}
+
+template <int NT>
+struct Ring {
+    static constexpr int R = NT > 8 ? NT : 8;  // fragments in flight per wave
+    static constexpr int CPI = R / NT;         // = chunks the ring runs ahead
+};
+
+// the ring starts with chunks 0 .. CPI-1;  wp = this lane's pointer to fragment (chunk 0, tile 0 of the wave)
+template <int NT>
+__device__ __forceinline__ void ring_fill(u16x8 (&w)[Ring<NT>::R], const u16x8* __restrict__ wp, int total) {
+    constexpr int CPI = Ring<NT>::CPI;
+#pragma unroll
+    for (int cc = 0; cc < CPI; ++cc) {
+        const int c = cc < total ? cc : total - 1;
+        const u16x8* p = wp + (size_t)c * (4 * NT * 64);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[cc * NT + t] = p[t * 64];
+    }
+}
+
+// acc[t][j] += W(chunks gc0 .. gc0+n) * B,  B = n k-chunks read from LDS rows of stride RS bytes
+// (`bsrc` = this lane's base: row e, k-group g).  Chunk (c, t) sits in ring slot (c % CPI)*NT + t and
+// is replaced, right after its 4 MFMAs, by chunk c+CPI of the weight stream (clamped at the end: a
+// few unused loads instead of a branch inside the unrolled body).  n % max(2, CPI) == 0.
+template <int NT, int RS>
+__device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][4], u16x8 (&w)[Ring<NT>::R],
+                                         const u16x8* __restrict__ wp, int gc0, int total,
+                                         const char* bsrc, int n) {
+    constexpr int CPI = Ring<NT>::CPI;
+    constexpr int U = CPI < 2 ? 2 : CPI;
+    u16x8 b[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[0][j] = *(const u16x8*)(bsrc + j * 16 * RS);
+    for (int c = 0; c < n; c += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cn = c + u + 1 < n ? c + u + 1 : n - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[(u + 1) & 1][j] = *(const u16x8*)(bsrc + j * 16 * RS + cn * 64);
+            const int gn = gc0 + c + u + CPI < total ? gc0 + c + u + CPI : total - 1;
+            const u16x8* wn = wp + (size_t)gn * (4 * NT * 64);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int slot = (u % CPI) * NT + t;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(w[slot]), as_bf16(b[u & 1][j]),
+                                                                        acc[t][j], 0, 0, 0);
+                w[slot] = wn[t * 64];
+            }
+        }
+    }
+}
+
+// bias -> LayerNorm over ALL features of the layer (this wave holds NT*16 of the 4*NT*16) -> activation
+template <int NT, int ACT>
+__device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT][4], const float* __restrict__ lnw,
+                                              const float* __restrict__ lnb, int act, float eps, float* red,
+                                              int wave, int ei, int g) {
+    constexpr float inv_n = 1.0f / (float)(4 * NT * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 v = acc[t][j];
+            s += (v.x + v.y) + (v.z + v.w);
+            q = fmaf(v.x, v.x, q);
+            q = fmaf(v.y, v.y, q);
+            q = fmaf(v.z, v.z, q);
+            q = fmaf(v.w, v.w, q);
+        }
+        s += __shfl_xor(s, 16);
+        q += __shfl_xor(q, 16);
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (g == 0) {
+            f32x2 sq;
+            sq.x = s;
+            sq.y = q;
+            *(f32x2*)(red + (wave * TE + j * 16 + ei) * 2) = sq;
+        }
+    }
+    __syncthreads();
+    float rstd[4], shift[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x2 sq = *(const f32x2*)(red + (w * TE + j * 16 + ei) * 2);
+            s += sq.x;
+            q += sq.y;
+        }
+        const float mean = s * inv_n;
+        const float var = fmaxf(fmaf(-mean, mean, q * inv_n), 0.f);
+        rstd[j] = 1.0f / sqrtf(var + eps);
+        shift[j] = -mean * rstd[j];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 w4 = *(const f32x4*)(lnw + t * 16);
+        const f32x4 b4 = *(const f32x4*)(lnb + t * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[t][j];
+            v.x = act_t<ACT>(fmaf(fmaf(v.x, rstd[j], shift[j]), w4.x, b4.x), act);
+            v.y = act_t<ACT>(fmaf(fmaf(v.y, rstd[j], shift[j]), w4.y, b4.y), act);
+            v.z = act_t<ACT>(fmaf(fmaf(v.z, rstd[j], shift[j]), w4.z, b4.z), act);
+            v.w = act_t<ACT>(fmaf(fmaf(v.w, rstd[j], shift[j]), w4.w, b4.w), act);
+            acc[t][j] = v;
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void init_bias(f32x4 (&acc)[NT][4], const float* __restrict__ b) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 bv = *(const f32x4*)(b + t * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = bv;
+    }
+}
+
+// activated tile -> bf16 hidden rows in LDS (row = edge, stride HRS bytes)
+template <int NT, int HRS>
+__device__ __forceinline__ void write_hidden(const f32x4 (&acc)[NT][4], char* hid_lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u16x4 o;
+            o[0] = bf16_bits(acc[t][j].x);
+            o[1] = bf16_bits(acc[t][j].y);
+            o[2] = bf16_bits(acc[t][j].z);
+            o[3] = bf16_bits(acc[t][j].w);
+            *(u16x4*)(hid_lane + j * 16 * HRS + t * 32) = o;
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void store_out(const f32x4 (&acc)[NT][4], const Args& a, long long e0, int wave, int ei,
+                                          int g) {
+    constexpr int NOUT = 4 * NT * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long e = e0 + j * 16 + ei;
+        if (e >= a.M) continue;
+        const size_t off = (size_t)e * NOUT + (size_t)(wave * NT * 16 + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 v = acc[t][j];
+            if (a.skip != nullptr) {
+                const u16x4 s = *(const u16x4*)(a.skip + off + t * 16);
+                v.x += bf16_float(s[0]);
+                v.y += bf16_float(s[1]);
+                v.z += bf16_float(s[2]);
+                v.w += bf16_float(s[3]);
+            }
+            u16x4 o;
+            o[0] = bf16_bits(v.x);
+            o[1] = bf16_bits(v.y);
+            o[2] = bf16_bits(v.z);
+            o[3] = bf16_bits(v.w);
+            *(u16x4*)(a.out + off + t * 16) = o;
+        }
+    }
+}
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// NTl: 16-feature tiles PER WAVE of layer l (= width_l / 64); PK: k-panel width of the input rows
+template <int NT1, int NT2, int NT3, int PK, int ACT_H, int ACT_O, int MINB>
+__global__ __launch_bounds__(256, MINB) void k_mlp_bf16_split(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HRS = NT1 * 64 * 2 + 16;  // hidden row stride (bytes): +16 spreads rows over the banks
+    constexpr int PRS = PK * 2 + 16;        // panel row stride
+    constexpr int PANEL = TE * PRS;
+    constexpr int REGION = cmax(TE * HRS, 2 * PANEL);  // the panels alias the hidden rows
+    constexpr int CPP = PK / 32;                      // k-chunks per panel
+    float* red = (float*)(smem + REGION);             // [4 waves][TE][sum, sumsq]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ei = lane & 15;
+    const int g = lane >> 4;
+    const long long e0 = (long long)blockIdx.x * TE;
+
+    // ---- input panels: thread (prow, pcol) moves 16 bytes of row prow (+RPP per pass) per panel
+    constexpr int LPR = PK * 2 / 16;
+    constexpr int RPP = 256 / LPR;
+    constexpr int NP = TE / RPP;
+    const int prow = tid / LPR;
+    const int pcol = tid % LPR;
+    const unsigned short* px[NP];
+    int r1[NP], r2[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        long long e = e0 + i * RPP + prow;
+        if (e >= a.M) e = a.M - 1;
+        const long long r0 = a.seg_index[0] != nullptr ? (long long)a.seg_index[0][e] : e;
+        px[i] = a.seg_table[0] + (size_t)r0 * (size_t)a.seg_width[0] + pcol * 8;
+        r1[i] = a.n_seg > 1 ? (a.seg_index[1] != nullptr ? a.seg_index[1][e] : (int)e) : 0;
+        r2[i] = a.n_seg > 2 ? (a.seg_index[2] != nullptr ? a.seg_index[2][e] : (int)e) : 0;
+    }
+    const int np = a.K1 / PK;
+    const int p1 = a.seg_width[0] / PK;
+    const int p2 = p1 + (a.n_seg > 1 ? a.seg_width[1] / PK : np);
+    u16x8 st[NP];
+    int pl = 0;  // next panel to load
+    auto load_panel = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            st[i] = *(const u16x8*)px[i];
+            px[i] += PK;
+        }
+        ++pl;
+        if (pl == p1) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) px[i] = a.seg_table[1] + (size_t)r1[i] * (size_t)a.seg_width[1] + pcol * 8;
+        }
+        if (pl == p2) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) px[i] = a.seg_table[2] + (size_t)r2[i] * (size_t)a.seg_width[2] + pcol * 8;
+        }
+    };
+    auto store_panel = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            *(u16x8*)(smem + buf * PANEL + (i * RPP + prow) * PRS + pcol * 16) = st[i];
+    };
+
+    // ---------------- layer 1: B = input panels
+    f32x4 acc1[NT1][4];
+    init_bias<NT1>(acc1, a.b[0] + wave * NT1 * 16 + 4 * g);
+    {
+        const int total = a.K1 / 32;
+        const u16x8* wp = (const u16x8*)a.W[0] + (size_t)(wave * NT1) * 64 + lane;
+        u16x8 w[Ring<NT1>::R];
+        load_panel();
+        ring_fill<NT1>(w, wp, total);
+        store_panel(0);
+        __syncthreads();
+        const char* blane = smem + ei * PRS + g * 16;
+        for (int p = 0; p < np; ++p) {
+            const bool more = p + 1 < np;
+            if (more) load_panel();
+            gemm_lds<NT1, PRS>(acc1, w, wp, p * CPP, total, blane + (p & 1) * PANEL, CPP);
+            if (more) store_panel((p + 1) & 1);
+            __syncthreads();
+        }
+    }
+    layernorm_act<NT1, ACT_H>(acc1, a.lnw[0] + wave * NT1 * 16 + 4 * g, a.lnb[0] + wave * NT1 * 16 + 4 * g, a.act[0],
+                              a.eps, red, wave, ei, g);
+    // (the barrier inside layernorm_act also means: every wave is done reading the panels)
+    write_hidden<NT1, HRS>(acc1, smem + ei * HRS + (wave * NT1 * 16 + 4 * g) * 2);
+    __syncthreads();
+
+    // ---------------- layer 2: B = hidden rows
+    f32x4 acc2[NT2][4];
+    init_bias<NT2>(acc2, a.b[1] + wave * NT2 * 16 + 4 * g);
+    {
+        const u16x8* wp = (const u16x8*)a.W[1] + (size_t)(wave * NT2) * 64 + lane;
+        u16x8 w[Ring<NT2>::R];
+        ring_fill<NT2>(w, wp, NT1 * 2);
+        gemm_lds<NT2, HRS>(acc2, w, wp, 0, NT1 * 2, smem + ei * HRS + g * 16, NT1 * 2);
+    }
+    if constexpr (NT3 == 0) {
+        layernorm_act<NT2, ACT_O>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
+                                  a.act[1], a.eps, red, wave, ei, g);
+        store_out<NT2>(acc2, a, e0, wave, ei, g);
+    } else {
+        layernorm_act<NT2, ACT_H>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
+                                  a.act[1], a.eps, red, wave, ei, g);
+        // in place: the barrier inside layernorm_act came after every wave's layer-2 reads
+        write_hidden<NT2, HRS>(acc2, smem + ei * HRS + (wave * NT2 * 16 + 4 * g) * 2);
+        __syncthreads();
+        f32x4 acc3[NT3][4];
+        init_bias<NT3>(acc3, a.b[2] + wave * NT3 * 16 + 4 * g);
+        {
+            const u16x8* wp = (const u16x8*)a.W[2] + (size_t)(wave * NT3) * 64 + lane;
+            u16x8 w[Ring<NT3>::R];
+            ring_fill<NT3>(w, wp, NT2 * 2);
+            gemm_lds<NT3, HRS>(acc3, w, wp, 0, NT2 * 2, smem + ei * HRS + g * 16, NT2 * 2);
+        }
+        layernorm_act<NT3, ACT_O>(acc3, a.lnw[2] + wave * NT3 * 16 + 4 * g, a.lnb[2] + wave * NT3 * 16 + 4 * g,
+                                  a.act[2], a.eps, red, wave, ei, g);
+        store_out<NT3>(acc3, a, e0, wave, ei, g);
+    }
+}
+
+template <int NT1, int NT2, int NT3, int MINB, int ACT_H, int ACT_O>
+static int launch_act(const Args& a, hipStream_t s) {
+    constexpr int PK = 128;
+    constexpr int HRS = NT1 * 64 * 2 + 16;
+    constexpr int PRS = PK * 2 + 16;
+    const size_t lds_bytes = (size_t)cmax(TE * HRS, 2 * TE * PRS) + 4 * TE * 2 * sizeof(float);
+    const unsigned grid = (unsigned)ceil_div(a.M, TE);
+    auto kern = k_mlp_bf16_split<NT1, NT2, NT3, PK, ACT_H, ACT_O, MINB>;
+    if (lds_bytes > 64 * 1024) {
+        HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes));
+    }
+    kern<<<grid, 256, lds_bytes, s>>>(a);
+    HGNN_CHECK_HIP(hipGetLastError());
+    return HGNN_OK;
+}
+
+template <int NT1, int NT2, int NT3, int MINB>
+static int launch(const Args& a, hipStream_t s) {
+    const int n = NT3 == 0 ? 2 : 3;
+    bool hidden_gelu = true;
+    for (int l = 0; l + 1 < n; ++l) hidden_gelu = hidden_gelu && a.act[l] == HGNN_ACT_GELU;
+    const int out = a.act[n - 1];
+    if (hidden_gelu && out == HGNN_ACT_TANH) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_TANH>(a, s);
+    if (hidden_gelu && out == HGNN_ACT_GELU) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_GELU>(a, s);
+    return launch_act<NT1, NT2, NT3, MINB, -1, -1>(a, s);
+}
+
+}  // namespace fs
+}  // namespace hgnn
+
+using namespace hgnn;
+
+extern "C" int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d) {
+    if (d == nullptr) return 0;
+    if (d->n_seg < 1 || d->n_seg > 3 || (d->n_layers != 2 && d->n_layers != 3)) return 0;
+    int k = 0;
+    for (int s = 0; s < d->n_seg; ++s) {
+        if (d->seg_width[s] <= 0 || d->seg_width[s] % 128 != 0) return 0;
+        k += d->seg_width[s];
+    }
+    if (k != d->width[0] || d->w0_cols != 0 || d->w_last_rows != 0) return 0;
+    const int n = d->n_layers;
+    for (int l = 0; l < n; ++l)
+        if (d->W[l] == nullptr || d->b[l] == nullptr || d->ln_w[l] == nullptr || d->ln_b[l] == nullptr) return 0;
+    if (d->save_pre[0] || d->save_pre[1] || d->save_pre[2]) return 0;
+    if (d->M < 0 || d->M > 0x7fffffffLL) return 0;
+    const int h = d->width[1];
+    const int o = d->width[n];
+    if (n == 3 && d->width[2] != h) return 0;
+    if (h != 2 * o) return 0;
+    return (o == 128 || o == 256 || o == 512) ? 1 : 0;
+}
+
+extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HGNN_REQUIRE(d != nullptr && out != nullptr, "hgnn_mlp_forward_bf16_split: NULL argument");
+    if (!hgnn_mlp_supported_bf16_split(d)) {
+        set_error("hgnn_mlp_forward_bf16_split: unsupported shape (K -> 2L (-> 2L) -> L, LayerNorm on every layer, "
+                  "L in {128,256,512}, every segment a multiple of 128 wide)");
+        return HGNN_ERR_UNSUPPORTED;
+    }
+    if (d->M == 0) return HGNN_OK;
+    fs::Args a;
+    for (int s = 0; s < 3; ++s) {
+        a.seg_table[s] = s < d->n_seg ? (const unsigned short*)d->seg_table[s] : nullptr;
+        a.seg_index[s] = s < d->n_seg ? d->seg_index[s] : nullptr;
+        a.seg_width[s] = s < d->n_seg ? d->seg_width[s] : 0;
+        if (s < d->n_seg) {
+            HGNN_REQUIRE(a.seg_table[s] != nullptr && (uintptr_t)a.seg_table[s] % 16 == 0,
+                         "hgnn_mlp_forward_bf16_split: segment table %d is NULL or not 16-byte aligned", s);
+        }
+    }
+    a.n_seg = d->n_seg;
+    a.K1 = d->width[0];
+    for (int l = 0; l < 3; ++l) {
+        const bool on = l < d->n_layers;
+        a.W[l] = on ? (const unsigned short*)d->W[l] : nullptr;
+        a.b[l] = on ? d->b[l] : nullptr;
+        a.lnw[l] = on ? d->ln_w[l] : nullptr;
+        a.lnb[l] = on ? d->ln_b[l] : nullptr;
+        a.act[l] = on ? d->act[l] : 0;
+        if (on) {
+            HGNN_REQUIRE((uintptr_t)a.W[l] % 16 == 0 && (uintptr_t)a.b[l] % 16 == 0 &&
+                             (uintptr_t)a.lnw[l] % 16 == 0 && (uintptr_t)a.lnb[l] % 16 == 0,
+                         "hgnn_mlp_forward_bf16_split: layer %d parameters must be 16-byte aligned", l);
+        }
+    }
+    a.eps = d->ln_eps;
+    a.skip = (const unsigned short*)d->skip;
+    a.out = (unsigned short*)out;
+    a.M = d->M;
+    HGNN_REQUIRE((uintptr_t)out % 8 == 0 && (uintptr_t)a.skip % 8 == 0,
+                 "hgnn_mlp_forward_bf16_split: out/skip must be 8-byte aligned");
+    const int o = d->width[d->n_layers];
+    if (d->n_layers == 2) {
+        switch (o) {
+            case 128: return fs::launch<4, 2, 0, 2>(a, stream);
+            case 256: return fs::launch<8, 4, 0, 2>(a, stream);
+            case 512: return fs::launch<16, 8, 0, 1>(a, stream);
+        }
+    } else {
+        switch (o) {
+            case 128: return fs::launch<4, 4, 2, 2>(a, stream);
+            case 256: return fs::launch<8, 8, 4, 2>(a, stream);
+            case 512: return fs::launch<16, 16, 8, 1>(a, stream);
+        }
+    }
+    set_error("hgnn_mlp_forward_bf16_split: no instantiation");
+    return HGNN_ERR_UNSUPPORTED;
+}

@@ -160,8 +160,36 @@ def _kslot_perm(k: int, device) -> torch.Tensor:
     return feat.reshape(-1)
 
 
-def _descriptor_bf16(net, segments, skip):
-    """descriptor for hgnn_mlp_forward_bf16: bf16 rows, bf16 (slot-ordered) weights, fp32 bias / LayerNorm"""
+def _fragment_order(W: torch.Tensor) -> torch.Tensor:
+    """bf16 W[F, K] in MFMA A-fragment order (include/hgnn_hip.h, hgnn_mlp_forward_bf16_split):
+    [k-chunk c][16-feature tile T][lane = 16*(k-group) + row][8 values]"""
+    F, K = W.shape
+    return W.view(F // 16, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
+
+
+_bf16_split = True
+
+
+def set_bf16_split(flag: bool) -> None:
+    """use the feature-split bf16 kernel for the wide layers (L >= 128) when it supports the shape"""
+    global _bf16_split
+    _bf16_split = bool(flag)
+
+
+def _wants_split(net, segments) -> bool:
+    layers = _parse(net)
+    if not _bf16_split or layers is None or len(layers) not in (2, 3):
+        return False
+    if any(int(t.shape[1]) % 128 for t, _ in segments):
+        return False
+    widths = [lin.out_features for lin, _, _ in layers]
+    o = widths[-1]
+    return o in (128, 256, 512) and all(w == 2 * o for w in widths[:-1])
+
+
+def _descriptor_bf16(net, segments, skip, split=False):
+    """descriptor for hgnn_mlp_forward_bf16 (bf16 rows, bf16 slot-ordered weights, fp32 bias / LayerNorm)
+    or, with ``split``, for hgnn_mlp_forward_bf16_split (weights in A-fragment order)"""
     layers = _parse(net)
     if layers is None or len(layers) not in (2, 3) or not (1 <= len(segments) <= 3):
         return None
@@ -197,11 +225,16 @@ def _descriptor_bf16(net, segments, skip):
         if lin.in_features != d.width[l] or not lin.weight.is_cuda:
             return None
         W = lin.weight.detach()
-        if l > 0:
-            if lin.in_features % 32:
+        if split:
+            if lin.in_features % 32 or lin.out_features % 64:
                 return None
-            W = W[:, _kslot_perm(lin.in_features, W.device)]
-        W = W.to(torch.bfloat16).contiguous()
+            W = _fragment_order(W.to(torch.bfloat16))
+        else:
+            if l > 0:
+                if lin.in_features % 32:
+                    return None
+                W = W[:, _kslot_perm(lin.in_features, W.device)]
+            W = W.to(torch.bfloat16).contiguous()
         small = [p.detach().float().contiguous() for p in (lin.bias, ln.weight, ln.bias)]
         keep += [W] + small
         d.W[l], d.b[l], d.ln_w[l], d.ln_b[l] = W.data_ptr(), small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr()
@@ -237,11 +270,17 @@ def supported(net, segments, skip) -> bool:
             tensors = [t for t, _ in segments] + ([skip] if skip is not None else []) + list(net.parameters())
             if any(t.requires_grad for t in tensors):
                 return False
+        split = _wants_split(net, segments)
         try:
-            desc = _descriptor_bf16(net, segments, skip)
+            desc = _descriptor_bf16(net, segments, skip, split)
         except RuntimeError:
             return False
-        return desc is not None and bool(_lib.load().hgnn_mlp_supported_bf16(ctypes.byref(desc[0])))
+        if desc is None:
+            return False
+        lib = _lib.load()
+        if split:
+            return bool(lib.hgnn_mlp_supported_bf16_split(ctypes.byref(desc[0])))
+        return bool(lib.hgnn_mlp_supported_bf16(ctypes.byref(desc[0])))
     if torch.is_grad_enabled():
         tensors = [t for t, _ in segments] + ([skip] if skip is not None else []) + list(net.parameters())
         if any(t.requires_grad for t in tensors):
@@ -257,7 +296,8 @@ def supported(net, segments, skip) -> bool:
 
 def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
     bf16 = _is_bf16(segments)
-    desc = _descriptor_bf16(net, segments, skip) if bf16 else _descriptor(net, segments, skip)
+    split = bf16 and _wants_split(net, segments)
+    desc = _descriptor_bf16(net, segments, skip, split) if bf16 else _descriptor(net, segments, skip)
     if desc is None:
         raise RuntimeError("fused_concat_mlp: unsupported arguments (call supported() first)")
     d, keep, M, n_out = desc
@@ -267,7 +307,10 @@ def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
         return out
     lib = _lib.load()
     with torch.cuda.device(dev):
-        if bf16:
+        if split:
+            _lib.check(lib.hgnn_mlp_forward_bf16_split(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
+                       "hgnn_mlp_forward_bf16_split")
+        elif bf16:
             _lib.check(lib.hgnn_mlp_forward_bf16(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
                        "hgnn_mlp_forward_bf16")
         else:

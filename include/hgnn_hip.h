@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 9
+#define HGNN_ABI_VERSION 10
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -237,6 +237,17 @@ int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_stream_t strea
  * LayerNorm on every layer, L in {32, 64, 128, 256}, every segment a multiple of 32 wide. */
 int hgnn_mlp_supported_bf16(const hgnn_mlp_desc* d);
 int hgnn_mlp_forward_bf16(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
+
+/* bf16, feature-split kernel for the wide layers (L in {128, 256, 512}; config 4 is L = 512): a
+ * workgroup owns 64 rows, each of its 4 waves a quarter of every layer's features; hidden
+ * activations cross waves through LDS, weights go straight from L2 to registers.  Same descriptor
+ * and arithmetic as hgnn_mlp_forward_bf16, except that W[l] (bf16) is stored in MFMA A-FRAGMENT
+ * ORDER, natural feature order for every layer:
+ *   element index = ((c * (F/16) + T) * 64 + lane) * 8 + i  holds  W[16T + lane%16][32c + 8(lane/16) + i]
+ * (F = out features, c = 32-wide k-chunk, T = 16-feature tile, lane = 0..63, i = 0..7).
+ * Supported: K -> 2L (-> 2L) -> L, LayerNorm on every layer, every segment a multiple of 128 wide. */
+int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d);
+int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -72,11 +72,16 @@ def test_bf16_unsupported_width_is_an_error():
         H.scatter_add(torch.zeros(10, 12).bfloat16().cuda(), torch.zeros(10, dtype=torch.long).cuda(), dim_size=2)
 
 
-@pytest.mark.parametrize("L,layers,nseg,M", [(32, 2, 3, 700), (64, 2, 3, 513), (128, 2, 3, 300), (256, 2, 3, 200),
-                                             (64, 3, 2, 400), (128, 3, 3, 129), (256, 3, 2, 90)])
-def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M):
+@pytest.mark.parametrize("L,layers,nseg,M,split", [
+    (32, 2, 3, 700, False), (64, 2, 3, 513, False), (128, 2, 3, 300, False), (256, 2, 3, 200, False),
+    (64, 3, 2, 400, False), (128, 3, 3, 129, False), (256, 3, 2, 90, False),
+    # the feature-split kernel (wide layers; L = 512 is BASELINE config 4): ragged tails, 1..3 segments
+    (128, 2, 3, 300, True), (256, 2, 3, 200, True), (512, 2, 3, 131, True), (128, 3, 3, 129, True),
+    (256, 3, 2, 90, True), (512, 3, 2, 70, True), (256, 2, 1, 64, True), (256, 2, 3, 1, True)])
+def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M, split):
     """bf16-MFMA fused MLP: against the fp32 oracle evaluated on the bf16-rounded inputs and weights"""
     from hierarchicalgnn_amd import fused, make_mlp
+    fused.set_bf16_split(split)
     from oracle import hgnn_oracle as O
     g = torch.Generator().manual_seed(L * 10 + layers)
     out_act = "Tanh" if layers == 2 else "GELU"
@@ -97,9 +102,13 @@ def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M):
     ref = O.mlp_apply(sd, "", x, layers, "GELU", out_act, True) + direct.float()
     net = net.cuda()
     segs = [(t.cuda(), None if i is None else i.cuda()) for t, i in segs_cpu]
-    with torch.no_grad():
-        assert fused.supported(net, segs, segs[-1][0])
-        out = fused.fused_concat_mlp(net, segs, segs[-1][0])
+    try:
+        with torch.no_grad():
+            assert fused._wants_split(net, segs) == split
+            assert fused.supported(net, segs, segs[-1][0])
+            out = fused.fused_concat_mlp(net, segs, segs[-1][0])
+    finally:
+        fused.set_bf16_split(True)
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
     # hidden activations are rounded to bf16 between layers: a few bf16 ulps at the output scale
     assert rel_err(out.float().cpu().numpy(), ref.numpy()) <= 4 * BF16_TOL

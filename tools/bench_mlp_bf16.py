@@ -44,14 +44,17 @@ res = {"L": L, "N": N, "M": M, "flop": flop}
 with torch.no_grad():
     seg32 = [(nodes32, graph[0]), (nodes32, graph[1]), (edges32, None)]
     seg16 = [(nodes16, graph[0]), (nodes16, graph[1]), (edges16, None)]
-    t = timeit(lambda: mlp.concat_mlp(net, seg32, skip=edges32))
-    res["fp32_fused_ms"], res["fp32_fused_tflops"] = t, flop / t / 1e9
+    if L <= 256:
+        t = timeit(lambda: mlp.concat_mlp(net, seg32, skip=edges32))
+        res["fp32_fused_ms"], res["fp32_fused_tflops"] = t, flop / t / 1e9
     from hierarchicalgnn_amd import _lib
     lib = _lib.load()
-    lib.hgnn_set_option(b"mlp_bf16_shape", 0)
-    t = timeit(lambda: mlp.concat_mlp(net, seg16, skip=edges16))
-    res["bf16_fused_16edges_2ring_ms"] = t
-    lib.hgnn_set_option(b"mlp_bf16_shape", 1)
+    if L <= 256:
+        fused.set_bf16_split(False)
+        lib.hgnn_set_option(b"mlp_bf16_shape", 1)
+        t = timeit(lambda: mlp.concat_mlp(net, seg16, skip=edges16))
+        res["bf16_fused_wave_owns_all_features_ms"] = t
+        fused.set_bf16_split(True)
     a = mlp.concat_mlp(net, seg16, skip=edges16)
     t = timeit(lambda: mlp.concat_mlp(net, seg16, skip=edges16))
     res["bf16_fused_ms"], res["bf16_fused_tflops"] = t, flop / t / 1e9
