@@ -21,6 +21,8 @@
 #include "mlp_common.h"
 
 namespace hgnn {
+extern int g_opt_mlp_ablate;
+int g_opt_mlp_split_variant = -1;  // hgnn_set_option("mlp_split_variant"): -1 auto, 0 counted waits, 2 burst
 namespace fs {
 
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
@@ -45,6 +47,9 @@ struct Args {
     const unsigned short* skip;
     unsigned short* out;
     long long M;
+    int ablate;  // DIAGNOSTIC (hgnn_set_option "mlp_ablate", wrong results): 1 = weights from chunk 0 only
+                 // (L1-resident), 2 = no LayerNorm / activation, 4 = only the first input panel is loaded,
+                 // 8 = no per-panel barriers, 16 = B reads from chunk 0 only
 };
 
 __device__ __forceinline__ bf16x8 as_bf16(u16x8 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -88,10 +93,10 @@ __device__ __forceinline__ void ring_fill(u16x8 (&w)[Ring<NT>::R], const u16x8* 
 // (`bsrc` = this lane's base: row e, k-group g).  Chunk (c, t) sits in ring slot (c % CPI)*NT + t and
 // is replaced, right after its 4 MFMAs, by chunk c+CPI of the weight stream (clamped at the end: a
 // few unused loads instead of a branch inside the unrolled body).  n % max(2, CPI) == 0.
-template <int NT, int RS>
+template <int NT, int RS, int VAR>
 __device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][4], u16x8 (&w)[Ring<NT>::R],
                                          const u16x8* __restrict__ wp, int gc0, int total,
-                                         const char* bsrc, int n) {
+                                         const char* bsrc, int n, int ablate) {
     constexpr int CPI = Ring<NT>::CPI;
     constexpr int U = CPI < 2 ? 2 : CPI;
     u16x8 b[2][4];
@@ -100,10 +105,23 @@ __device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][4], u16x8 (&w)[Ring<NT
     for (int c = 0; c < n; c += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int cn = c + u + 1 < n ? c + u + 1 : n - 1;
+            // VAR 2 (two waves per SIMD, 32 MFMAs per chunk): a chunk = one uninterrupted burst.  Park
+            // ONCE until the whole chunk's operands have landed, then issue its MFMAs (and the next
+            // chunk's loads) back to back; the partner wave's loads fly meanwhile.  With per-fragment
+            // counted waits both waves stall in small steps all the time (A/B in one process at
+            // L=256: 3.3 -> 2.8 ms; s_setprio around the burst: no change).  Shorter chunks (L=128)
+            // and one wave per SIMD (L=512) are faster with the counted waits (VAR 0).
+            if (VAR >= 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            int cn = c + u + 1 < n ? c + u + 1 : n - 1;
+            if (ablate & 16) cn = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[(u + 1) & 1][j] = *(const u16x8*)(bsrc + j * 16 * RS + cn * 64);
-            const int gn = gc0 + c + u + CPI < total ? gc0 + c + u + CPI : total - 1;
+            // pin the issue order (hipcc otherwise sinks every load to just before its first use,
+            // i.e. an L2 round trip behind 4 MFMAs): the next chunk's B reads first, then per tile
+            // 4 MFMAs followed by the ring refill that runs 8 fragments ahead
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            int gn = gc0 + c + u + CPI < total ? gc0 + c + u + CPI : total - 1;
+            if (ablate & 1) gn = 0;
             const u16x8* wn = wp + (size_t)gn * (4 * NT * 64);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -113,6 +131,8 @@ __device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][4], u16x8 (&w)[Ring<NT
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(w[slot]), as_bf16(b[u & 1][j]),
                                                                         acc[t][j], 0, 0, 0);
                 w[slot] = wn[t * 64];
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
     }
@@ -122,8 +142,12 @@ __device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][4], u16x8 (&w)[Ring<NT
 template <int NT, int ACT>
 __device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT][4], const float* __restrict__ lnw,
                                               const float* __restrict__ lnb, int act, float eps, float* red,
-                                              int wave, int ei, int g) {
+                                              int wave, int ei, int g, int ablate) {
     constexpr float inv_n = 1.0f / (float)(4 * NT * 16);
+    if (ablate & 2) {
+        __syncthreads();
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float s = 0.f, q = 0.f;
@@ -238,7 +262,7 @@ __device__ __forceinline__ void store_out(const f32x4 (&acc)[NT][4], const Args&
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // NTl: 16-feature tiles PER WAVE of layer l (= width_l / 64); PK: k-panel width of the input rows
-template <int NT1, int NT2, int NT3, int PK, int ACT_H, int ACT_O, int MINB>
+template <int NT1, int NT2, int NT3, int PK, int ACT_H, int ACT_O, int MINB, int VAR>
 __global__ __launch_bounds__(256, MINB) void k_mlp_bf16_split(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HRS = NT1 * 64 * 2 + 16;  // hidden row stride (bytes): +16 spreads rows over the banks
@@ -311,15 +335,15 @@ __global__ __launch_bounds__(256, MINB) void k_mlp_bf16_split(const Args a) {
         __syncthreads();
         const char* blane = smem + ei * PRS + g * 16;
         for (int p = 0; p < np; ++p) {
-            const bool more = p + 1 < np;
+            const bool more = p + 1 < np && !(a.ablate & 4);
             if (more) load_panel();
-            gemm_lds<NT1, PRS>(acc1, w, wp, p * CPP, total, blane + (p & 1) * PANEL, CPP);
+            gemm_lds<NT1, PRS, VAR>(acc1, w, wp, p * CPP, total, blane + (p & 1) * PANEL, CPP, a.ablate);
             if (more) store_panel((p + 1) & 1);
-            __syncthreads();
+            if (!(a.ablate & 8)) __syncthreads();
         }
     }
     layernorm_act<NT1, ACT_H>(acc1, a.lnw[0] + wave * NT1 * 16 + 4 * g, a.lnb[0] + wave * NT1 * 16 + 4 * g, a.act[0],
-                              a.eps, red, wave, ei, g);
+                              a.eps, red, wave, ei, g, a.ablate);
     // (the barrier inside layernorm_act also means: every wave is done reading the panels)
     write_hidden<NT1, HRS>(acc1, smem + ei * HRS + (wave * NT1 * 16 + 4 * g) * 2);
     __syncthreads();
@@ -331,15 +355,15 @@ __global__ __launch_bounds__(256, MINB) void k_mlp_bf16_split(const Args a) {
         const u16x8* wp = (const u16x8*)a.W[1] + (size_t)(wave * NT2) * 64 + lane;
         u16x8 w[Ring<NT2>::R];
         ring_fill<NT2>(w, wp, NT1 * 2);
-        gemm_lds<NT2, HRS>(acc2, w, wp, 0, NT1 * 2, smem + ei * HRS + g * 16, NT1 * 2);
+        gemm_lds<NT2, HRS, VAR>(acc2, w, wp, 0, NT1 * 2, smem + ei * HRS + g * 16, NT1 * 2, a.ablate);
     }
     if constexpr (NT3 == 0) {
         layernorm_act<NT2, ACT_O>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
-                                  a.act[1], a.eps, red, wave, ei, g);
+                                  a.act[1], a.eps, red, wave, ei, g, a.ablate);
         store_out<NT2>(acc2, a, e0, wave, ei, g);
     } else {
         layernorm_act<NT2, ACT_H>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
-                                  a.act[1], a.eps, red, wave, ei, g);
+                                  a.act[1], a.eps, red, wave, ei, g, a.ablate);
         // in place: the barrier inside layernorm_act came after every wave's layer-2 reads
         write_hidden<NT2, HRS>(acc2, smem + ei * HRS + (wave * NT2 * 16 + 4 * g) * 2);
         __syncthreads();
@@ -349,22 +373,22 @@ __global__ __launch_bounds__(256, MINB) void k_mlp_bf16_split(const Args a) {
             const u16x8* wp = (const u16x8*)a.W[2] + (size_t)(wave * NT3) * 64 + lane;
             u16x8 w[Ring<NT3>::R];
             ring_fill<NT3>(w, wp, NT2 * 2);
-            gemm_lds<NT3, HRS>(acc3, w, wp, 0, NT2 * 2, smem + ei * HRS + g * 16, NT2 * 2);
+            gemm_lds<NT3, HRS, VAR>(acc3, w, wp, 0, NT2 * 2, smem + ei * HRS + g * 16, NT2 * 2, a.ablate);
         }
         layernorm_act<NT3, ACT_O>(acc3, a.lnw[2] + wave * NT3 * 16 + 4 * g, a.lnb[2] + wave * NT3 * 16 + 4 * g,
-                                  a.act[2], a.eps, red, wave, ei, g);
+                                  a.act[2], a.eps, red, wave, ei, g, a.ablate);
         store_out<NT3>(acc3, a, e0, wave, ei, g);
     }
 }
 
-template <int NT1, int NT2, int NT3, int MINB, int ACT_H, int ACT_O>
+template <int NT1, int NT2, int NT3, int MINB, int ACT_H, int ACT_O, int VAR>
 static int launch_act(const Args& a, hipStream_t s) {
     constexpr int PK = 128;
     constexpr int HRS = NT1 * 64 * 2 + 16;
     constexpr int PRS = PK * 2 + 16;
     const size_t lds_bytes = (size_t)cmax(TE * HRS, 2 * TE * PRS) + 4 * TE * 2 * sizeof(float);
     const unsigned grid = (unsigned)ceil_div(a.M, TE);
-    auto kern = k_mlp_bf16_split<NT1, NT2, NT3, PK, ACT_H, ACT_O, MINB>;
+    auto kern = k_mlp_bf16_split<NT1, NT2, NT3, PK, ACT_H, ACT_O, MINB, VAR>;
     if (lds_bytes > 64 * 1024) {
         HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
@@ -380,9 +404,17 @@ static int launch(const Args& a, hipStream_t s) {
     bool hidden_gelu = true;
     for (int l = 0; l + 1 < n; ++l) hidden_gelu = hidden_gelu && a.act[l] == HGNN_ACT_GELU;
     const int out = a.act[n - 1];
-    if (hidden_gelu && out == HGNN_ACT_TANH) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_TANH>(a, s);
-    if (hidden_gelu && out == HGNN_ACT_GELU) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_GELU>(a, s);
-    return launch_act<NT1, NT2, NT3, MINB, -1, -1>(a, s);
+    // burst schedule where a chunk is 32 MFMAs and two waves share a SIMD (see gemm_lds)
+    constexpr int AUTO = (NT1 == 8 && MINB == 2) ? 2 : 0;
+    const int var = g_opt_mlp_split_variant < 0 ? AUTO : g_opt_mlp_split_variant;
+    if (var == 2) {
+        if (hidden_gelu && out == HGNN_ACT_TANH) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_TANH, 2>(a, s);
+        if (hidden_gelu && out == HGNN_ACT_GELU) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_GELU, 2>(a, s);
+        return launch_act<NT1, NT2, NT3, MINB, -1, -1, 2>(a, s);
+    }
+    if (hidden_gelu && out == HGNN_ACT_TANH) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_TANH, 0>(a, s);
+    if (hidden_gelu && out == HGNN_ACT_GELU) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_GELU, 0>(a, s);
+    return launch_act<NT1, NT2, NT3, MINB, -1, -1, 0>(a, s);
 }
 
 }  // namespace fs
@@ -449,6 +481,7 @@ extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hg
     a.skip = (const unsigned short*)d->skip;
     a.out = (unsigned short*)out;
     a.M = d->M;
+    a.ablate = g_opt_mlp_ablate;
     HGNN_REQUIRE((uintptr_t)out % 8 == 0 && (uintptr_t)a.skip % 8 == 0,
                  "hgnn_mlp_forward_bf16_split: out/skip must be 8-byte aligned");
     const int o = d->width[d->n_layers];

@@ -24,6 +24,7 @@ namespace hgnn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern int g_opt_mlp_ablate;
+extern int g_opt_mlp_split_variant;
 extern int g_opt_mlp_bf16_shape;
 
 static int g_opt_nt_loads = 1;   // non-temporal loads for once-read source rows
@@ -492,7 +493,8 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     else if (!strcmp(name, "seg_unroll")) g_opt_seg_unroll = value;
     else if (!strcmp(name, "seg_wpb")) g_opt_seg_wpb = value;
     else if (!strcmp(name, "seg_xcd")) g_opt_seg_xcd = value;
-    else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 7;
+    else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 31;
+    else if (!strcmp(name, "mlp_split_variant")) g_opt_mlp_split_variant = value;
     else if (!strcmp(name, "mlp_bf16_shape")) g_opt_mlp_bf16_shape = value;
     else {
         set_error("hgnn_set_option: unknown option '%s'", name);

@@ -105,8 +105,13 @@ int hgnn_sizeof_mlp_desc(void);
  *   "nt_loads", "nt_stores", "seg_unroll", "seg_wpb", "seg_xcd"   K1..K6 launch shape / cache policy
  *   "mlp_bf16_shape" bf16 MLP launch shape: 0 = 16 edges/wave, 2-deep weight ring; 1 (default) = 32
  *                  edges/wave, 3-deep ring for wide layers
- *   "mlp_ablate"   DIAGNOSTIC bits, results are WRONG: 1 skip LayerNorm/act, 2 skip weight DMA,
- *                  4 skip barriers (used to price those parts; tools/tune_mlp.py) */
+ *   "mlp_split_variant" schedule of the feature-split bf16 MLP: -1 (default) per shape, 0 counted
+ *                  per-fragment waits, 2 one wait per k-chunk ("burst")
+ *   "mlp_ablate"   DIAGNOSTIC bits, results are WRONG.  fp32 / bf16 kernels: 1 skip LayerNorm/act,
+ *                  2 skip weight DMA, 4 skip barriers (tools/tune_mlp.py); feature-split bf16
+ *                  kernel: 1 weights from chunk 0 only, 2 skip LayerNorm/act, 4 load only the first
+ *                  input panel, 8 skip the per-panel barriers, 16 LDS operand reads from chunk 0
+ *                  only (tools/tune_mlp_split.py) */
 int hgnn_set_option(const char* name, int value);
 
 /* Fills n_rows/n_dst/n_src/chunk/max_* of `plan` (pointers untouched).
