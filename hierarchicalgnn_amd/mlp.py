@@ -33,5 +33,12 @@ def concat_mlp(net: nn.Sequential, segments: Sequence[Segment], skip: Optional[t
     for table, index in segments:
         parts.append(table if index is None else gather_rows(table, index))
     x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
-    y = net(x)
+    if x.dtype == torch.bfloat16 and next(net.parameters()).dtype == torch.float32:
+        # bf16 feature rows with fp32 master weights (hparams["feature_dtype"] = "bf16"): library
+        # GEMMs in bf16, LayerNorm statistics in fp32 -- what autocast does
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net(x)
+        y = y.to(torch.bfloat16)
+    else:
+        y = net(x)
     return y if skip is None else y + skip

@@ -24,6 +24,11 @@ from .plan import memo
 from .utils import make_mlp
 
 
+def _bf16_features(hparams) -> bool:
+    """hparams["feature_dtype"] in ("bf16", "bfloat16"): an MI355X-side switch, absent = the reference's fp32"""
+    return str(hparams.get("feature_dtype", "fp32")).lower() in ("bf16", "bfloat16")
+
+
 def _dst_sorted(graph):
     """(order, graph[:, order], inverse of order) for the stable sort of ``graph`` by destination"""
     order = torch.argsort(graph[1], stable=True)
@@ -79,6 +84,10 @@ class InteractionGNNBlock(nn.Module):
             order, graph, inverse = memo(graph, "dst_sorted", lambda g=graph: _dst_sorted(g))
         nodes = _maybe_checkpoint(self._ckpt, self._encode_nodes, x)              # IN.py:84
         edges = _maybe_checkpoint(self._ckpt, self._encode_edges, x, graph)       # IN.py:85
+        if _bf16_features(self.hparams):
+            # BASELINE config 4: latent rows in bf16 (fp32 master weights, fp32 accumulation and
+            # LayerNorm inside the kernels); encoders, embeddings and heads stay fp32
+            nodes, edges = nodes.bfloat16(), edges.bfloat16()
         for cell in self.ignn_cells:                                              # IN.py:87-88
             nodes, edges = cell(nodes, edges, graph)
         if order is not None and restore_order:
@@ -87,7 +96,7 @@ class InteractionGNNBlock(nn.Module):
             graph, order = graph_in, None
         emb = None
         if self.emb:
-            emb = nn.functional.normalize(self.output_layer(nodes))
+            emb = nn.functional.normalize(self.output_layer(nodes.float()))
         return emb, nodes, edges, graph, order
 
     def forward(self, x, graph):
@@ -111,6 +120,7 @@ class EC_InteractionGNN(nn.Module):
     def forward(self, x, graph):
         directed_graph = memo(graph, "directed", lambda: torch.cat([graph, graph.flip(0)], dim=1))  # IN.py:122
         nodes, edges = self.ignn_block(x, directed_graph)
+        edges = edges.float()                                                     # the head is fp32
         e = graph.shape[1]
         # IN.py:126 -- relies on the ORIGINAL edge order: edges[:E] pairs with edges[E:]
         scores = concat_mlp(self.edge_classifier, [(edges[:e], None), (edges[e:], None)]).squeeze(-1)
@@ -191,7 +201,8 @@ class HierarchicalGNNBlock(nn.Module):
         # HGNN_GMM.py:269 -- L1-normalised rows, weighted, summed per supernode (K5, one fused kernel)
         pooled = gather_scale_scatter(nodes, bipartite_graph[0], bipartite_graph[1], means.shape[0],
                                       bipartite_edge_weights, row_scale=l1_row_scale(nodes))
-        supernodes = torch.cat([means, _maybe_checkpoint(self._ckpt, self._encode_supernodes, pooled)], dim=-1)
+        supernodes = torch.cat([means.to(nodes.dtype),
+                                _maybe_checkpoint(self._ckpt, self._encode_supernodes, pooled)], dim=-1)
         superedges = _maybe_checkpoint(self._ckpt, self._encode_superedges, supernodes, super_graph)
         for cell in self.hgnn_cells:                                              # HGNN_GMM.py:275-284
             nodes, edges, supernodes, superedges = cell(nodes, edges, supernodes, superedges, graph,
@@ -237,7 +248,7 @@ class BC_MessagePassing(nn.Module):
     def score(self, nodes, supernodes, bipartite_graph):
         """HGNN_GMM.py:342-344"""
         s = concat_mlp(self.bipartite_output_layer,
-                       [(nodes, bipartite_graph[0]), (supernodes, bipartite_graph[1])]).squeeze(-1)
+                       [(nodes.float(), bipartite_graph[0]), (supernodes.float(), bipartite_graph[1])]).squeeze(-1)
         return torch.sigmoid(s)
 
 

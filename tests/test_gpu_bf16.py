@@ -135,3 +135,61 @@ def test_interaction_cell_bf16_tracks_the_fp32_reference(latent):
     assert fused.stats["fused_calls"] == n0 + 2 and on.dtype == torch.bfloat16
     assert rel_err(on.float().cpu().numpy(), z["out_nodes"]) <= 6 * BF16_TOL
     assert rel_err(oe.float().cpu().numpy(), z["out_edges"]) <= 6 * BF16_TOL
+
+
+def test_ec_in_forward_with_bf16_latents_tracks_the_reference_scores():
+    """hparams["feature_dtype"] = "bf16" (BASELINE config 4 dtype at model level): fp32 encoders and head,
+    bf16 latent rows through the 14 cells; scores stay close to the reference's fp32 scores"""
+    import numpy as np
+    from conftest import load_golden
+    from hierarchicalgnn_amd.models import EC_InteractionGNN
+    z = load_golden("ec_in_L32.npz")
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    hp["feature_dtype"] = "bf16"
+    model = EC_InteractionGNN(hp)
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")})
+    model = model.cuda().eval()
+    x = torch.from_numpy(z["x"]).cuda()
+    graph = torch.from_numpy(z["edge_index"]).cuda()
+    with torch.no_grad():
+        scores = model(x, graph)
+    assert scores.dtype == torch.float32 and scores.shape == z["scores"].shape
+    d = np.abs(scores.cpu().numpy() - z["scores"])
+    assert d.mean() <= 0.01 and d.max() <= 0.1, (d.mean(), d.max())
+    # training-mode call in bf16: autograd through the bf16 HIP ops + autocast library MLPs
+    scores = model(x, graph)
+    scores.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_bc_hgnn_block_with_bf16_latents_tracks_the_reference():
+    """BC-HGNN-GMM message passing in bf16 on the hierarchy captured from the reference's forward"""
+    import numpy as np
+    from conftest import load_golden
+    from hierarchicalgnn_amd.models import BC_MessagePassing
+    z = load_golden("bc_hgnn_L32.npz")
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    hp["feature_dtype"] = "bf16"
+    model = BC_MessagePassing(hp)
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}, strict=True)
+    model = model.cuda().eval()
+    x = torch.from_numpy(z["x"]).cuda()
+    graph = torch.from_numpy(z["edge_index"]).cuda()
+    t = lambda k: torch.from_numpy(z[k]).cuda()
+    with torch.no_grad():
+        directed, emb, nodes, edges, order = model.embed(x, graph)
+        assert nodes.dtype == torch.bfloat16 and edges.dtype == torch.bfloat16 and emb.dtype == torch.float32
+        assert rel_err(emb.cpu().numpy(), z["embeddings"]) <= 0.05
+        means = t("cell0.in.supernodes")[:, :hp["emb_dim"]].contiguous()
+        bg, bw = t("cell0.in.bipartite_graph"), t("cell0.in.bipartite_edge_weights")
+        sg, sw = t("cell0.in.super_graph"), t("cell0.in.super_edge_weights")
+        n_out, sn_out, _, _ = model.hgnn_block(nodes, edges, directed, means, bg, bw, sg, sw)
+        assert n_out.dtype == torch.bfloat16 and sn_out.dtype == torch.bfloat16
+        last = int(z["n_cells"]) - 1
+        assert rel_err(n_out.float().cpu().numpy(), z[f"cell{last}.out.nodes"]) <= 0.1
+        scores = model.score(n_out, sn_out, t("bipartite_graph"))
+        d = np.abs(scores.cpu().numpy() - z["bipartite_scores"])
+        assert d.mean() <= 0.02, (d.mean(), d.max())
+        # and the whole forward (own hierarchy decision) runs
+        bgr, s, e = model(x, graph)
+        assert s.dtype == torch.float32 and torch.isfinite(s).all() and bgr.shape[1] == s.shape[0]

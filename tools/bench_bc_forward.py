@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE config 3 shape: the tensor arithmetic of BC-HGNN-GMM (latent=256, 6 + 6 cells) on the
 synthetic event with a synthetic hierarchy (S=10k clusters from phi-wedges; kNN graphs rebuilt by
-the HIP kNN kernel).  Inference forward, fused vs library.  Usage: bench_bc_forward.py [L]"""
+the HIP kNN kernel).  Inference forward, fused vs library.  Usage: bench_bc_forward.py [L] [bf16]
+(`bench_bc_forward.py 512 bf16` = BASELINE config 4: latent 512, bf16 latent rows, kNN graphs rebuilt per forward)"""
 import json
 import os
 import sys
@@ -12,11 +13,13 @@ from hierarchicalgnn_amd import fused, synth
 from hierarchicalgnn_amd.models import BC_MessagePassing
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+BF16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"
 torch.manual_seed(1236)
 hp = dict(spatial_channels=3, latent=L, hidden=2 * L, emb_dim=8, n_interaction_graph_iters=6,
           n_hierarchical_graph_iters=6, nb_node_layer=3, nb_edge_layer=2, output_layers=3,
           hidden_output_activation="Tanh", hidden_activation="GELU", layernorm=True, share_weight=False,
-          bipartitegraph_sparsity=5, supergraph_sparsity=10, min_cluster_size=3, cluster_granularity=5)
+          bipartitegraph_sparsity=5, supergraph_sparsity=10, min_cluster_size=3, cluster_granularity=5,
+          feature_dtype="bf16" if BF16 else "fp32")
 model = BC_MessagePassing(hp).cuda().eval()
 model.hgnn_block.super_graph_construction.knn_radius.fill_(2.0)
 model.hgnn_block.bipartite_graph_construction.knn_radius.fill_(2.0)
@@ -26,7 +29,7 @@ S = 10_000
 # stand-in for the (host-side, out-of-scope) GMM + connected-components clustering: phi-z cells
 clusters = ((x[:, 1] + 1) * 0.5 * 100).long().clamp(0, 99) * 100 + ((x[:, 2] + 1) * 0.5 * 100).long().clamp(0, 99)
 _, clusters = torch.unique(clusters, return_inverse=True)
-res = {"model": "BC-HGNN-GMM message passing", "latent": L, "N": x.shape[0], "E": ei.shape[1],
+res = {"model": "BC-HGNN-GMM message passing", "latent": L, "feature_dtype": hp["feature_dtype"], "N": x.shape[0], "E": ei.shape[1],
        "clusters": int(clusters.max()) + 1, "params": sum(p.numel() for p in model.parameters())}
 
 
