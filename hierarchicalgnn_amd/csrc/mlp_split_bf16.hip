@@ -22,6 +22,7 @@
 
 namespace hgnn {
 extern int g_opt_mlp_ablate;
+int g_opt_mlp_split_shape = 0;     // hgnn_set_option("mlp_split_shape"): 0 = 64 rows x 4 waves, 1 = 128 rows x 8 waves (L=256)
 int g_opt_mlp_split_variant = -1;  // hgnn_set_option("mlp_split_variant"): -1 auto, 0 counted waits, 2 burst
 namespace fs {
 
@@ -30,7 +31,6 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TE = 64;  // edges per workgroup (4 MFMA column tiles)
 
 struct Args {
     const unsigned short* seg_table[3];
@@ -77,13 +77,13 @@ struct Ring {
 };
 
 // the ring starts with chunks 0 .. CPI-1;  wp = this lane's pointer to fragment (chunk 0, tile 0 of the wave)
-template <int NT>
+template <int NT, int NW>
 __device__ __forceinline__ void ring_fill(u16x8 (&w)[Ring<NT>::R], const u16x8* __restrict__ wp, int total) {
     constexpr int CPI = Ring<NT>::CPI;
 #pragma unroll
     for (int cc = 0; cc < CPI; ++cc) {
         const int c = cc < total ? cc : total - 1;
-        const u16x8* p = wp + (size_t)c * (4 * NT * 64);
+        const u16x8* p = wp + (size_t)c * (NW * NT * 64);
 #pragma unroll
         for (int t = 0; t < NT; ++t) w[cc * NT + t] = p[t * 64];
     }
@@ -93,15 +93,19 @@ __device__ __forceinline__ void ring_fill(u16x8 (&w)[Ring<NT>::R], const u16x8* 
 // (`bsrc` = this lane's base: row e, k-group g).  Chunk (c, t) sits in ring slot (c % CPI)*NT + t and
 // is replaced, right after its 4 MFMAs, by chunk c+CPI of the weight stream (clamped at the end: a
 // few unused loads instead of a branch inside the unrolled body).  n % max(2, CPI) == 0.
-template <int NT, int RS, int VAR>
-__device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][4], u16x8 (&w)[Ring<NT>::R],
+template <int NT, int RS, int VAR, int NW, int NJ>
+__device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][NJ], u16x8 (&w)[Ring<NT>::R],
                                          const u16x8* __restrict__ wp, int gc0, int total,
                                          const char* bsrc, int n, int ablate) {
     constexpr int CPI = Ring<NT>::CPI;
     constexpr int U = CPI < 2 ? 2 : CPI;
-    u16x8 b[2][4];
+    // NJ = 4: the next chunk's B fragments are read into a second register set at the start of the
+    // chunk; NJ = 8 (32 registers per set): each fragment is re-read IN PLACE right after its last
+    // MFMA of the chunk (the last weight tile), 8 MFMAs = 128 cycles before its next use
+    constexpr bool INPLACE = NJ > 4;
+    u16x8 b[INPLACE ? 1 : 2][NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[0][j] = *(const u16x8*)(bsrc + j * 16 * RS);
+    for (int j = 0; j < NJ; ++j) b[0][j] = *(const u16x8*)(bsrc + j * 16 * RS);
     for (int c = 0; c < n; c += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -114,42 +118,54 @@ __device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][4], u16x8 (&w)[Ring<NT
             if (VAR >= 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             int cn = c + u + 1 < n ? c + u + 1 : n - 1;
             if (ablate & 16) cn = 0;
+            constexpr int cur = INPLACE ? 0 : 0;
+            const int bi = INPLACE ? 0 : (u & 1);
+            if constexpr (!INPLACE) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[(u + 1) & 1][j] = *(const u16x8*)(bsrc + j * 16 * RS + cn * 64);
-            // pin the issue order (hipcc otherwise sinks every load to just before its first use,
-            // i.e. an L2 round trip behind 4 MFMAs): the next chunk's B reads first, then per tile
-            // 4 MFMAs followed by the ring refill that runs 8 fragments ahead
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                for (int j = 0; j < NJ; ++j) b[(u + 1) & 1][j] = *(const u16x8*)(bsrc + j * 16 * RS + cn * 64);
+                // pin the issue order (hipcc otherwise sinks every load to just before its first use,
+                // i.e. an L2 round trip behind 4 MFMAs): the next chunk's B reads first, then per tile
+                // NJ MFMAs followed by the ring refill that runs 8 fragments ahead
+                __builtin_amdgcn_sched_group_barrier(0x100, NJ, 0);
+            }
+            (void)cur;
             int gn = gc0 + c + u + CPI < total ? gc0 + c + u + CPI : total - 1;
             if (ablate & 1) gn = 0;
-            const u16x8* wn = wp + (size_t)gn * (4 * NT * 64);
+            const u16x8* wn = wp + (size_t)gn * (NW * NT * 64);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int slot = (u % CPI) * NT + t;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(w[slot]), as_bf16(b[u & 1][j]),
+                for (int j = 0; j < NJ; ++j) {
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(w[slot]), as_bf16(b[bi][j]),
                                                                         acc[t][j], 0, 0, 0);
+                    if (INPLACE && t == NT - 1) {
+                        b[0][j] = *(const u16x8*)(bsrc + j * 16 * RS + cn * 64);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
                 w[slot] = wn[t * 64];
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (!(INPLACE && t == NT - 1)) __builtin_amdgcn_sched_group_barrier(0x008, NJ, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
     }
 }
 
-// bias -> LayerNorm over ALL features of the layer (this wave holds NT*16 of the 4*NT*16) -> activation
-template <int NT, int ACT>
-__device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT][4], const float* __restrict__ lnw,
+// bias -> LayerNorm over ALL features of the layer (this wave holds NT*16 of the NW*NT*16) -> activation
+template <int NT, int ACT, int NW, int NJ>
+__device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT][NJ], const float* __restrict__ lnw,
                                               const float* __restrict__ lnb, int act, float eps, float* red,
                                               int wave, int ei, int g, int ablate) {
-    constexpr float inv_n = 1.0f / (float)(4 * NT * 16);
+    constexpr float inv_n = 1.0f / (float)(NW * NT * 16);
+    constexpr int TE = 16 * NJ;
     if (ablate & 2) {
         __syncthreads();
         return;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -172,12 +188,12 @@ __device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT][4], const float* 
         }
     }
     __syncthreads();
-    float rstd[4], shift[4];
+    float rstd[NJ], shift[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const f32x2 sq = *(const f32x2*)(red + (w * TE + j * 16 + ei) * 2);
             s += sq.x;
             q += sq.y;
@@ -192,7 +208,7 @@ __device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT][4], const float* 
         const f32x4 w4 = *(const f32x4*)(lnw + t * 16);
         const f32x4 b4 = *(const f32x4*)(lnb + t * 16);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             f32x4 v = acc[t][j];
             v.x = act_t<ACT>(fmaf(fmaf(v.x, rstd[j], shift[j]), w4.x, b4.x), act);
             v.y = act_t<ACT>(fmaf(fmaf(v.y, rstd[j], shift[j]), w4.y, b4.y), act);
@@ -203,23 +219,23 @@ __device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT][4], const float* 
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void init_bias(f32x4 (&acc)[NT][4], const float* __restrict__ b) {
+template <int NT, int NJ>
+__device__ __forceinline__ void init_bias(f32x4 (&acc)[NT][NJ], const float* __restrict__ b) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const f32x4 bv = *(const f32x4*)(b + t * 16);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = bv;
+        for (int j = 0; j < NJ; ++j) acc[t][j] = bv;
     }
 }
 
 // activated tile -> bf16 hidden rows in LDS (row = edge, stride HRS bytes)
-template <int NT, int HRS>
-__device__ __forceinline__ void write_hidden(const f32x4 (&acc)[NT][4], char* hid_lane) {
+template <int NT, int HRS, int NJ>
+__device__ __forceinline__ void write_hidden(const f32x4 (&acc)[NT][NJ], char* hid_lane) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             u16x4 o;
             o[0] = bf16_bits(acc[t][j].x);
             o[1] = bf16_bits(acc[t][j].y);
@@ -230,12 +246,12 @@ __device__ __forceinline__ void write_hidden(const f32x4 (&acc)[NT][4], char* hi
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void store_out(const f32x4 (&acc)[NT][4], const Args& a, long long e0, int wave, int ei,
+template <int NT, int NW, int NJ>
+__device__ __forceinline__ void store_out(const f32x4 (&acc)[NT][NJ], const Args& a, long long e0, int wave, int ei,
                                           int g) {
-    constexpr int NOUT = 4 * NT * 16;
+    constexpr int NOUT = NW * NT * 16;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const long long e = e0 + j * 16 + ei;
         if (e >= a.M) continue;
         const size_t off = (size_t)e * NOUT + (size_t)(wave * NT * 16 + 4 * g);
@@ -261,16 +277,20 @@ __device__ __forceinline__ void store_out(const f32x4 (&acc)[NT][4], const Args&
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-// NTl: 16-feature tiles PER WAVE of layer l (= width_l / 64); PK: k-panel width of the input rows
-template <int NT1, int NT2, int NT3, int PK, int ACT_H, int ACT_O, int MINB, int VAR>
-__global__ __launch_bounds__(256, MINB) void k_mlp_bf16_split(const Args a) {
+// NW waves x NJ 16-row tiles per workgroup; NTl: 16-feature tiles PER WAVE of layer l (= width_l / (16 NW));
+// PK: k-panel width of the input rows
+template <int NT1, int NT2, int NT3, int PK, int ACT_H, int ACT_O, int MINB, int VAR, int NW, int NJ>
+__global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int HRS = NT1 * 64 * 2 + 16;  // hidden row stride (bytes): +16 spreads rows over the banks
+    constexpr int TE = 16 * NJ;              // rows per workgroup
+    constexpr int NTHR = NW * 64;
+    constexpr int NC2 = NT1 * NW / 2;        // k-chunks of the hidden layers (width / 32)
+    constexpr int HRS = NT1 * NW * 32 + 16;  // hidden row stride (bytes): +16 spreads rows over the banks
     constexpr int PRS = PK * 2 + 16;        // panel row stride
     constexpr int PANEL = TE * PRS;
     constexpr int REGION = cmax(TE * HRS, 2 * PANEL);  // the panels alias the hidden rows
     constexpr int CPP = PK / 32;                      // k-chunks per panel
-    float* red = (float*)(smem + REGION);             // [4 waves][TE][sum, sumsq]
+    float* red = (float*)(smem + REGION);             // [NW waves][TE][sum, sumsq]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(256, MINB) void k_mlp_bf16_split(const Args a) {
 
     // ---- input panels: thread (prow, pcol) moves 16 bytes of row prow (+RPP per pass) per panel
     constexpr int LPR = PK * 2 / 16;
-    constexpr int RPP = 256 / LPR;
+    constexpr int RPP = NTHR / LPR;
     constexpr int NP = TE / RPP;
     const int prow = tid / LPR;
     const int pcol = tid % LPR;
@@ -323,98 +343,99 @@ __global__ __launch_bounds__(256, MINB) void k_mlp_bf16_split(const Args a) {
     };
 
     // ---------------- layer 1: B = input panels
-    f32x4 acc1[NT1][4];
-    init_bias<NT1>(acc1, a.b[0] + wave * NT1 * 16 + 4 * g);
+    f32x4 acc1[NT1][NJ];
+    init_bias<NT1, NJ>(acc1, a.b[0] + wave * NT1 * 16 + 4 * g);
     {
         const int total = a.K1 / 32;
         const u16x8* wp = (const u16x8*)a.W[0] + (size_t)(wave * NT1) * 64 + lane;
         u16x8 w[Ring<NT1>::R];
         load_panel();
-        ring_fill<NT1>(w, wp, total);
+        ring_fill<NT1, NW>(w, wp, total);
         store_panel(0);
         __syncthreads();
         const char* blane = smem + ei * PRS + g * 16;
         for (int p = 0; p < np; ++p) {
             const bool more = p + 1 < np && !(a.ablate & 4);
             if (more) load_panel();
-            gemm_lds<NT1, PRS, VAR>(acc1, w, wp, p * CPP, total, blane + (p & 1) * PANEL, CPP, a.ablate);
+            gemm_lds<NT1, PRS, VAR, NW, NJ>(acc1, w, wp, p * CPP, total, blane + (p & 1) * PANEL, CPP, a.ablate);
             if (more) store_panel((p + 1) & 1);
             if (!(a.ablate & 8)) __syncthreads();
         }
     }
-    layernorm_act<NT1, ACT_H>(acc1, a.lnw[0] + wave * NT1 * 16 + 4 * g, a.lnb[0] + wave * NT1 * 16 + 4 * g, a.act[0],
+    layernorm_act<NT1, ACT_H, NW, NJ>(acc1, a.lnw[0] + wave * NT1 * 16 + 4 * g, a.lnb[0] + wave * NT1 * 16 + 4 * g, a.act[0],
                               a.eps, red, wave, ei, g, a.ablate);
     // (the barrier inside layernorm_act also means: every wave is done reading the panels)
-    write_hidden<NT1, HRS>(acc1, smem + ei * HRS + (wave * NT1 * 16 + 4 * g) * 2);
+    write_hidden<NT1, HRS, NJ>(acc1, smem + ei * HRS + (wave * NT1 * 16 + 4 * g) * 2);
     __syncthreads();
 
     // ---------------- layer 2: B = hidden rows
-    f32x4 acc2[NT2][4];
-    init_bias<NT2>(acc2, a.b[1] + wave * NT2 * 16 + 4 * g);
+    f32x4 acc2[NT2][NJ];
+    init_bias<NT2, NJ>(acc2, a.b[1] + wave * NT2 * 16 + 4 * g);
     {
         const u16x8* wp = (const u16x8*)a.W[1] + (size_t)(wave * NT2) * 64 + lane;
         u16x8 w[Ring<NT2>::R];
-        ring_fill<NT2>(w, wp, NT1 * 2);
-        gemm_lds<NT2, HRS, VAR>(acc2, w, wp, 0, NT1 * 2, smem + ei * HRS + g * 16, NT1 * 2, a.ablate);
+        ring_fill<NT2, NW>(w, wp, NC2);
+        gemm_lds<NT2, HRS, VAR, NW, NJ>(acc2, w, wp, 0, NC2, smem + ei * HRS + g * 16, NC2, a.ablate);
     }
     if constexpr (NT3 == 0) {
-        layernorm_act<NT2, ACT_O>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
+        layernorm_act<NT2, ACT_O, NW, NJ>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
                                   a.act[1], a.eps, red, wave, ei, g, a.ablate);
-        store_out<NT2>(acc2, a, e0, wave, ei, g);
+        store_out<NT2, NW, NJ>(acc2, a, e0, wave, ei, g);
     } else {
-        layernorm_act<NT2, ACT_H>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
+        layernorm_act<NT2, ACT_H, NW, NJ>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
                                   a.act[1], a.eps, red, wave, ei, g, a.ablate);
         // in place: the barrier inside layernorm_act came after every wave's layer-2 reads
-        write_hidden<NT2, HRS>(acc2, smem + ei * HRS + (wave * NT2 * 16 + 4 * g) * 2);
+        write_hidden<NT2, HRS, NJ>(acc2, smem + ei * HRS + (wave * NT2 * 16 + 4 * g) * 2);
         __syncthreads();
-        f32x4 acc3[NT3][4];
-        init_bias<NT3>(acc3, a.b[2] + wave * NT3 * 16 + 4 * g);
+        f32x4 acc3[NT3][NJ];
+        init_bias<NT3, NJ>(acc3, a.b[2] + wave * NT3 * 16 + 4 * g);
         {
             const u16x8* wp = (const u16x8*)a.W[2] + (size_t)(wave * NT3) * 64 + lane;
             u16x8 w[Ring<NT3>::R];
-            ring_fill<NT3>(w, wp, NT2 * 2);
-            gemm_lds<NT3, HRS, VAR>(acc3, w, wp, 0, NT2 * 2, smem + ei * HRS + g * 16, NT2 * 2, a.ablate);
+            ring_fill<NT3, NW>(w, wp, NC2);
+            gemm_lds<NT3, HRS, VAR, NW, NJ>(acc3, w, wp, 0, NC2, smem + ei * HRS + g * 16, NC2, a.ablate);
         }
-        layernorm_act<NT3, ACT_O>(acc3, a.lnw[2] + wave * NT3 * 16 + 4 * g, a.lnb[2] + wave * NT3 * 16 + 4 * g,
+        layernorm_act<NT3, ACT_O, NW, NJ>(acc3, a.lnw[2] + wave * NT3 * 16 + 4 * g, a.lnb[2] + wave * NT3 * 16 + 4 * g,
                                   a.act[2], a.eps, red, wave, ei, g, a.ablate);
-        store_out<NT3>(acc3, a, e0, wave, ei, g);
+        store_out<NT3, NW, NJ>(acc3, a, e0, wave, ei, g);
     }
 }
 
-template <int NT1, int NT2, int NT3, int MINB, int ACT_H, int ACT_O, int VAR>
+template <int NT1, int NT2, int NT3, int MINB, int ACT_H, int ACT_O, int VAR, int NW, int NJ>
 static int launch_act(const Args& a, hipStream_t s) {
     constexpr int PK = 128;
-    constexpr int HRS = NT1 * 64 * 2 + 16;
+    constexpr int TE = 16 * NJ;
+    constexpr int HRS = NT1 * NW * 32 + 16;
     constexpr int PRS = PK * 2 + 16;
-    const size_t lds_bytes = (size_t)cmax(TE * HRS, 2 * TE * PRS) + 4 * TE * 2 * sizeof(float);
+    const size_t lds_bytes = (size_t)cmax(TE * HRS, 2 * TE * PRS) + NW * TE * 2 * sizeof(float);
     const unsigned grid = (unsigned)ceil_div(a.M, TE);
-    auto kern = k_mlp_bf16_split<NT1, NT2, NT3, PK, ACT_H, ACT_O, MINB, VAR>;
+    auto kern = k_mlp_bf16_split<NT1, NT2, NT3, PK, ACT_H, ACT_O, MINB, VAR, NW, NJ>;
     if (lds_bytes > 64 * 1024) {
         HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
     }
-    kern<<<grid, 256, lds_bytes, s>>>(a);
+    kern<<<grid, NW * 64, lds_bytes, s>>>(a);
     HGNN_CHECK_HIP(hipGetLastError());
     return HGNN_OK;
 }
 
-template <int NT1, int NT2, int NT3, int MINB>
+template <int NT1, int NT2, int NT3, int MINB, int NW = 4, int NJ = 4>
 static int launch(const Args& a, hipStream_t s) {
     const int n = NT3 == 0 ? 2 : 3;
     bool hidden_gelu = true;
     for (int l = 0; l + 1 < n; ++l) hidden_gelu = hidden_gelu && a.act[l] == HGNN_ACT_GELU;
     const int out = a.act[n - 1];
     // burst schedule where a chunk is 32 MFMAs and two waves share a SIMD (see gemm_lds)
-    constexpr int AUTO = (NT1 == 8 && MINB == 2) ? 2 : 0;
+    constexpr int AUTO = (NT1 * NJ == 32 && MINB * NW == 8) ? 2 : 0;
     const int var = g_opt_mlp_split_variant < 0 ? AUTO : g_opt_mlp_split_variant;
     if (var == 2) {
-        if (hidden_gelu && out == HGNN_ACT_TANH) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_TANH, 2>(a, s);
-        if (hidden_gelu && out == HGNN_ACT_GELU) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_GELU, 2>(a, s);
-        return launch_act<NT1, NT2, NT3, MINB, -1, -1, 2>(a, s);
+        if (hidden_gelu && out == HGNN_ACT_TANH) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_TANH, 2, NW, NJ>(a, s);
+        if (hidden_gelu && out == HGNN_ACT_GELU) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_GELU, 2, NW, NJ>(a, s);
+        return launch_act<NT1, NT2, NT3, MINB, -1, -1, 2, NW, NJ>(a, s);
     }
-    if (hidden_gelu && out == HGNN_ACT_TANH) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_TANH, 0>(a, s);
-    if (hidden_gelu && out == HGNN_ACT_GELU) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_GELU, 0>(a, s);
-    return launch_act<NT1, NT2, NT3, MINB, -1, -1, 0>(a, s);
+    if (hidden_gelu && out == HGNN_ACT_TANH) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_TANH, 0, NW, NJ>(a, s);
+    if (hidden_gelu && out == HGNN_ACT_GELU) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_GELU, 0, NW, NJ>(a, s);
+    return launch_act<NT1, NT2, NT3, MINB, -1, -1, 0, NW, NJ>(a, s);
 }
 
 }  // namespace fs
@@ -488,7 +509,9 @@ extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hg
     if (d->n_layers == 2) {
         switch (o) {
             case 128: return fs::launch<4, 2, 0, 2>(a, stream);
-            case 256: return fs::launch<8, 4, 0, 2>(a, stream);
+            case 256:
+                if (g_opt_mlp_split_shape == 1) return fs::launch<4, 2, 0, 1, 8, 8>(a, stream);
+                return fs::launch<8, 4, 0, 2>(a, stream);
             case 512: return fs::launch<16, 8, 0, 1>(a, stream);
         }
     } else {

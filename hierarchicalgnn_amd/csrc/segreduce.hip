@@ -25,6 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern int g_opt_mlp_ablate;
 extern int g_opt_mlp_split_variant;
+extern int g_opt_mlp_split_shape;
 extern int g_opt_mlp_bf16_shape;
 
 static int g_opt_nt_loads = 1;   // non-temporal loads for once-read source rows
@@ -495,6 +496,7 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     else if (!strcmp(name, "seg_xcd")) g_opt_seg_xcd = value;
     else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 31;
     else if (!strcmp(name, "mlp_split_variant")) g_opt_mlp_split_variant = value;
+    else if (!strcmp(name, "mlp_split_shape")) g_opt_mlp_split_shape = value;
     else if (!strcmp(name, "mlp_bf16_shape")) g_opt_mlp_bf16_shape = value;
     else {
         set_error("hgnn_set_option: unknown option '%s'", name);
