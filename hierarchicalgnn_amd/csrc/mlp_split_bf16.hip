@@ -22,7 +22,7 @@
 
 namespace hgnn {
 extern int g_opt_mlp_ablate;
-int g_opt_mlp_split_shape = 0;     // hgnn_set_option("mlp_split_shape"): 0 = 64 rows x 4 waves, 1 = 128 rows x 8 waves (L=256)
+int g_opt_mlp_split_shape = -1;    // hgnn_set_option("mlp_split_shape"): -1 auto, 0 = 4 waves x 64 rows, 1 = 8 waves (L=256: x 128 rows, L=512: x 64 rows)
 int g_opt_mlp_split_variant = -1;  // hgnn_set_option("mlp_split_variant"): -1 auto, 0 counted waits, 2 burst
 namespace fs {
 
@@ -426,7 +426,7 @@ static int launch(const Args& a, hipStream_t s) {
     for (int l = 0; l + 1 < n; ++l) hidden_gelu = hidden_gelu && a.act[l] == HGNN_ACT_GELU;
     const int out = a.act[n - 1];
     // burst schedule where a chunk is 32 MFMAs and two waves share a SIMD (see gemm_lds)
-    constexpr int AUTO = (NT1 * NJ == 32 && MINB * NW == 8) ? 2 : 0;
+    constexpr int AUTO = (NT1 == 8 && NW == 4 && MINB == 2) ? 2 : 0;
     const int var = g_opt_mlp_split_variant < 0 ? AUTO : g_opt_mlp_split_variant;
     if (var == 2) {
         if (hidden_gelu && out == HGNN_ACT_TANH) return launch_act<NT1, NT2, NT3, MINB, HGNN_ACT_GELU, HGNN_ACT_TANH, 2, NW, NJ>(a, s);
@@ -510,15 +510,20 @@ extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hg
         switch (o) {
             case 128: return fs::launch<4, 2, 0, 2>(a, stream);
             case 256:
-                if (g_opt_mlp_split_shape == 1) return fs::launch<4, 2, 0, 1, 8, 8>(a, stream);
+                if (g_opt_mlp_split_shape == 1) return fs::launch<4, 2, 0, 1, 8, 8>(a, stream);  // A/B only: slower
                 return fs::launch<8, 4, 0, 2>(a, stream);
-            case 512: return fs::launch<16, 8, 0, 1>(a, stream);
+            case 512:
+                // 8 waves share the 64 rows (2 per SIMD instead of 1): 8.6 vs 9.6 ms at M = 2M
+                if (g_opt_mlp_split_shape != 0) return fs::launch<8, 4, 0, 1, 8, 4>(a, stream);
+                return fs::launch<16, 8, 0, 1>(a, stream);
         }
     } else {
         switch (o) {
             case 128: return fs::launch<4, 4, 2, 2>(a, stream);
             case 256: return fs::launch<8, 8, 4, 2>(a, stream);
-            case 512: return fs::launch<16, 16, 8, 1>(a, stream);
+            case 512:
+                if (g_opt_mlp_split_shape != 0) return fs::launch<8, 8, 4, 1, 8, 4>(a, stream);
+                return fs::launch<16, 16, 8, 1>(a, stream);
         }
     }
     set_error("hgnn_mlp_forward_bf16_split: no instantiation");

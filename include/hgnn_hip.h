@@ -105,7 +105,8 @@ int hgnn_sizeof_mlp_desc(void);
  *   "nt_loads", "nt_stores", "seg_unroll", "seg_wpb", "seg_xcd"   K1..K6 launch shape / cache policy
  *   "mlp_bf16_shape" bf16 MLP launch shape: 0 = 16 edges/wave, 2-deep weight ring; 1 (default) = 32
  *                  edges/wave, 3-deep ring for wide layers
- *   "mlp_split_shape" feature-split bf16 MLP at L=256: 0 (default) 64 rows x 4 waves, 1 = 128 rows x 8 waves
+ *   "mlp_split_shape" feature-split bf16 MLP: -1 (default) per shape, 0 = 4 waves x 64 rows, 1 = 8 waves
+ *                  (L=256: x 128 rows; L=512: x 64 rows, the default there)
  *   "mlp_split_variant" schedule of the feature-split bf16 MLP: -1 (default) per shape, 0 counted
  *                  per-fragment waits, 2 one wait per k-chunk ("burst")
  *   "mlp_ablate"   DIAGNOSTIC bits, results are WRONG.  fp32 / bf16 kernels: 1 skip LayerNorm/act,
