@@ -23,7 +23,11 @@ from .ops import gather_rows
 Segment = Tuple[torch.Tensor, Optional[torch.Tensor]]  # (table, index or None)
 
 
-def concat_mlp(net: nn.Sequential, segments: Sequence[Segment], skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+def concat_mlp(net: nn.Sequential, segments: Sequence[Segment], skip: Optional[torch.Tensor] = None,
+               bf16_tail: bool = False) -> torch.Tensor:
+    """``bf16_tail`` (bf16 latent mode, encoders): when an fp32-input MLP has no fused kernel, keep its
+    first Linear in fp32 (hit coordinates must not be rounded to 8 bits) and run the rest -- the wide
+    GEMMs -- in bf16; the result is bf16."""
     from . import fused
     if fused.supported(net, segments, skip):
         return fused.fused_concat_mlp(net, segments, skip)
@@ -33,7 +37,12 @@ def concat_mlp(net: nn.Sequential, segments: Sequence[Segment], skip: Optional[t
     for table, index in segments:
         parts.append(table if index is None else gather_rows(table, index))
     x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
-    if x.dtype == torch.bfloat16 and next(net.parameters()).dtype == torch.float32:
+    if bf16_tail and x.dtype == torch.float32 and x.is_cuda and isinstance(net[0], nn.Linear) and len(net) > 1:
+        y = net[0](x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net[1:](y)
+        y = y.to(torch.bfloat16)
+    elif x.dtype == torch.bfloat16 and next(net.parameters()).dtype == torch.float32:
         # bf16 feature rows with fp32 master weights (hparams["feature_dtype"] = "bf16"): library
         # GEMMs in bf16, LayerNorm statistics in fp32 -- what autocast does
         with torch.autocast("cuda", dtype=torch.bfloat16):

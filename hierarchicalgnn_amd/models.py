@@ -29,6 +29,14 @@ def _bf16_features(hparams) -> bool:
     return str(hparams.get("feature_dtype", "fp32")).lower() in ("bf16", "bfloat16")
 
 
+def _head_input(t, hparams):
+    """score heads: fp32 (the fused fp32 head kernel) up to latent 256; beyond that there is no fused
+    fp32 kernel and, in bf16 mode, the library path runs the head's wide GEMMs in bf16 (autocast)"""
+    if t.dtype == torch.float32 or int(hparams["latent"]) > 256:
+        return t
+    return t.float()
+
+
 def _dst_sorted(graph):
     """(order, graph[:, order], inverse of order) for the stable sort of ``graph`` by destination"""
     order = torch.argsort(graph[1], stable=True)
@@ -62,10 +70,10 @@ class InteractionGNNBlock(nn.Module):
         self._ckpt = bool(hparams.get("checkpointing", True))
 
     def _encode_nodes(self, x):
-        return concat_mlp(self.node_encoder, [(x, None)])
+        return concat_mlp(self.node_encoder, [(x, None)], bf16_tail=_bf16_features(self.hparams))
 
     def _encode_edges(self, x, graph):
-        return concat_mlp(self.edge_encoder, [(x, graph[0]), (x, graph[1])])
+        return concat_mlp(self.edge_encoder, [(x, graph[0]), (x, graph[1])], bf16_tail=_bf16_features(self.hparams))
 
     def run(self, x, graph, restore_order=True):
         """The block on the destination-sorted layout.  Returns (emb or None, nodes, edges, graph_used,
@@ -120,11 +128,11 @@ class EC_InteractionGNN(nn.Module):
     def forward(self, x, graph):
         directed_graph = memo(graph, "directed", lambda: torch.cat([graph, graph.flip(0)], dim=1))  # IN.py:122
         nodes, edges = self.ignn_block(x, directed_graph)
-        edges = edges.float()                                                     # the head is fp32
+        edges = _head_input(edges, self.hparams)
         e = graph.shape[1]
         # IN.py:126 -- relies on the ORIGINAL edge order: edges[:E] pairs with edges[E:]
         scores = concat_mlp(self.edge_classifier, [(edges[:e], None), (edges[e:], None)]).squeeze(-1)
-        return torch.sigmoid(scores)
+        return torch.sigmoid(scores.float())
 
 
 class HierarchicalGNNBlock(nn.Module):
@@ -248,8 +256,9 @@ class BC_MessagePassing(nn.Module):
     def score(self, nodes, supernodes, bipartite_graph):
         """HGNN_GMM.py:342-344"""
         s = concat_mlp(self.bipartite_output_layer,
-                       [(nodes.float(), bipartite_graph[0]), (supernodes.float(), bipartite_graph[1])]).squeeze(-1)
-        return torch.sigmoid(s)
+                       [(_head_input(nodes, self.hparams), bipartite_graph[0]),
+                        (_head_input(supernodes, self.hparams), bipartite_graph[1])]).squeeze(-1)
+        return torch.sigmoid(s.float())
 
 
 class GraphedInference:

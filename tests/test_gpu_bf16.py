@@ -199,3 +199,28 @@ def test_bc_hgnn_block_with_bf16_latents_tracks_the_reference():
         # and the whole forward (own hierarchy decision) runs
         bgr, s, e = model(x, graph)
         assert s.dtype == torch.float32 and torch.isfinite(s).all() and bgr.shape[1] == s.shape[0]
+
+
+def test_latent512_bf16_mode_matches_its_fp32_model():
+    """BASELINE config 4 widths (latent 512): encoders (fp32 first layer, bf16 tail), bf16 cells on the
+    feature-split kernel, bf16 head -- against the same weights run in fp32"""
+    from hierarchicalgnn_amd import fused, synth
+    from hierarchicalgnn_amd.models import EC_InteractionGNN
+    hp = dict(spatial_channels=3, latent=512, hidden=1024, n_interaction_graph_iters=2, nb_node_layer=3,
+              nb_edge_layer=2, output_layers=3, hidden_output_activation="GELU", hidden_activation="GELU",
+              layernorm=True, share_weight=False)
+    torch.manual_seed(5)
+    ref_model = EC_InteractionGNN(hp).cuda().eval()
+    model = EC_InteractionGNN(dict(hp, feature_dtype="bf16")).cuda().eval()
+    model.load_state_dict(ref_model.state_dict())
+    x, ei = synth.trackml_event(1500, 9000, seed=3)
+    x, ei = x.cuda(), ei.cuda()
+    n0 = fused.stats["fused_calls"]
+    with torch.no_grad():
+        ref = ref_model(x, ei)
+        n1 = fused.stats["fused_calls"]
+        out = model(x, ei)
+    assert fused.stats["fused_calls"] - n1 >= 4 and n1 == n0      # 2 cells x (node + edge) fused in bf16; none in fp32
+    assert out.dtype == torch.float32 and out.shape == ref.shape
+    d = (out - ref).abs()
+    assert float(d.mean()) <= 0.01 and float(d.max()) <= 0.1, (float(d.mean()), float(d.max()))
