@@ -15,17 +15,22 @@ namespace hgnn {
 constexpr int kKnnTile = 256;
 constexpr int kKnnDMax = 16;
 
-template <int K>
-__global__ __launch_bounds__(256) void k_knn_radius(const float* __restrict__ query, int64_t nq,
-                                                    const float* __restrict__ points, int64_t np, int D,
-                                                    float r2, int64_t* __restrict__ idx_out,
-                                                    float* __restrict__ d2_out) {
-    __shared__ float tile[kKnnTile * kKnnDMax];
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+typedef float knn_f32x4 __attribute__((ext_vector_type(4)));
+
+// DP = D padded to 4 / 8 / 16 with zeros (adds fmaf(0, 0, d2) = d2: same distances, no per-dimension
+// conditionals, candidates read as broadcast 16-byte LDS vectors); BLOCK = 64 for few queries (the
+// super graph: ~10k queries would otherwise occupy 36 of the 256 CUs), 256 otherwise
+template <int K, int DP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_knn_radius(const float* __restrict__ query, int64_t nq,
+                                                      const float* __restrict__ points, int64_t np, int D,
+                                                      float r2, int64_t* __restrict__ idx_out,
+                                                      float* __restrict__ d2_out) {
+    __shared__ __attribute__((aligned(16))) float tile[kKnnTile * DP];
+    const int64_t q = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     const bool active = q < nq;
-    float qv[kKnnDMax];
+    float qv[DP];
 #pragma unroll
-    for (int d = 0; d < kKnnDMax; ++d) qv[d] = (active && d < D) ? query[q * D + d] : 0.f;
+    for (int d = 0; d < DP; ++d) qv[d] = (active && d < D) ? query[q * D + d] : 0.f;
     float best_d[K];
     int best_i[K];
 #pragma unroll
@@ -36,30 +41,50 @@ __global__ __launch_bounds__(256) void k_knn_radius(const float* __restrict__ qu
     for (int64_t base = 0; base < np; base += kKnnTile) {
         const int n = (np - base) < kKnnTile ? (int)(np - base) : kKnnTile;
         __syncthreads();
-        for (int t = threadIdx.x; t < n * D; t += blockDim.x) tile[t] = points[base * D + t];
+        for (int t = threadIdx.x; t < n * DP; t += BLOCK) {
+            const int pt = t / DP, d = t % DP;
+            tile[t] = d < D ? points[(base + pt) * D + d] : 0.f;
+        }
         __syncthreads();
         if (active) {
-            for (int j = 0; j < n; ++j) {
-                float d2 = 0.f;
+            // 4 candidates per step: their distances first (independent LDS reads in flight together),
+            // then the (rare) insertions in candidate order -- same result as one at a time
+            for (int j0 = 0; j0 < n; j0 += 4) {
+                float d2u[4];
 #pragma unroll
-                for (int d = 0; d < kKnnDMax; ++d)
-                    if (d < D) {
-                        const float t = qv[d] - tile[j * D + d];
+                for (int u = 0; u < 4; ++u) {
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int v = 0; v < DP / 4; ++v) {
+                        const knn_f32x4 p4 = *(const knn_f32x4*)(tile + (j0 + u) * DP + v * 4);
+                        float t = qv[v * 4 + 0] - p4.x;
+                        d2 = fmaf(t, t, d2);
+                        t = qv[v * 4 + 1] - p4.y;
+                        d2 = fmaf(t, t, d2);
+                        t = qv[v * 4 + 2] - p4.z;
+                        d2 = fmaf(t, t, d2);
+                        t = qv[v * 4 + 3] - p4.w;
                         d2 = fmaf(t, t, d2);
                     }
-                if (d2 < r2 && d2 < best_d[K - 1]) {
-                    // insertion into the sorted list (static indexing: stays in registers)
-                    float cd = d2;
-                    int ci = (int)(base + j);
+                    d2u[u] = (j0 + u) < n ? d2 : 3.0e38f;   // rows past the tile's end hold stale data
+                }
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        if (cd < best_d[k]) {
-                            const float td = best_d[k];
-                            const int ti = best_i[k];
-                            best_d[k] = cd;
-                            best_i[k] = ci;
-                            cd = td;
-                            ci = ti;
+                for (int u = 0; u < 4; ++u) {
+                    const float d2 = d2u[u];
+                    if (d2 < r2 && d2 < best_d[K - 1]) {
+                        // insertion into the sorted list (static indexing: stays in registers)
+                        float cd = d2;
+                        int ci = (int)(base + j0 + u);
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            if (cd < best_d[k]) {
+                                const float td = best_d[k];
+                                const int ti = best_i[k];
+                                best_d[k] = cd;
+                                best_i[k] = ci;
+                                cd = td;
+                                ci = ti;
+                            }
                         }
                     }
                 }
@@ -73,6 +98,22 @@ __global__ __launch_bounds__(256) void k_knn_radius(const float* __restrict__ qu
             if (d2_out != nullptr) d2_out[q * K + k] = best_i[k] >= 0 ? best_d[k] : -1.f;
         }
     }
+}
+
+template <int K>
+static void launch_knn(const float* query, int64_t nq, const float* points, int64_t np, int D, float r2,
+                       int64_t* idx_out, float* d2_out, hipStream_t stream) {
+    const bool small = nq < 65536;
+    const unsigned grid = (unsigned)ceil_div(nq, small ? 64 : 256);
+#define HGNN_KNN_DP(DP)                                                                                      \
+    do {                                                                                                     \
+        if (small) k_knn_radius<K, DP, 64><<<grid, 64, 0, stream>>>(query, nq, points, np, D, r2, idx_out, d2_out); \
+        else k_knn_radius<K, DP, 256><<<grid, 256, 0, stream>>>(query, nq, points, np, D, r2, idx_out, d2_out);     \
+    } while (0)
+    if (D <= 4) HGNN_KNN_DP(4);
+    else if (D <= 8) HGNN_KNN_DP(8);
+    else HGNN_KNN_DP(16);
+#undef HGNN_KNN_DP
 }
 
 }  // namespace hgnn
@@ -90,10 +131,8 @@ extern "C" int hgnn_knn_radius_f32(const float* query, int64_t nq, const float* 
     if (nq == 0) return HGNN_OK;
     HGNN_REQUIRE(query != nullptr && idx_out != nullptr && (np == 0 || points != nullptr),
                  "hgnn_knn_radius_f32: NULL pointer");
-    const unsigned grid = (unsigned)ceil_div(nq, 256);
     const float r2 = radius * radius;
-#define HGNN_KNN(KK)                                                                                   \
-    k_knn_radius<KK><<<grid, 256, 0, stream>>>(query, nq, points, np, D, r2, idx_out, dist2_out)
+#define HGNN_KNN(KK) launch_knn<KK>(query, nq, points, np, D, r2, idx_out, dist2_out, stream)
     switch (K) {
         case 1: HGNN_KNN(1); break;
         case 2: HGNN_KNN(2); break;
