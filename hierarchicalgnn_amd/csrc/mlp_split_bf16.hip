@@ -113,9 +113,10 @@ __device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][NJ], u16x8 (&w)[Ring<N
             // ONCE until the whole chunk's operands have landed, then issue its MFMAs (and the next
             // chunk's loads) back to back; the partner wave's loads fly meanwhile.  With per-fragment
             // counted waits both waves stall in small steps all the time (A/B in one process at
-            // L=256: 3.3 -> 2.8 ms; s_setprio around the burst: no change).  Shorter chunks (L=128)
+            // L=256: 3.3 -> 2.7 ms; s_setprio around the burst: no change; a counted wait every 4
+            // fragments instead: 4.5 ms).  Shorter chunks (L=128)
             // and one wave per SIMD (L=512) are faster with the counted waits (VAR 0).
-            if (VAR >= 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (VAR == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             int cn = c + u + 1 < n ? c + u + 1 : n - 1;
             if (ablate & 16) cn = 0;
             constexpr int cur = INPLACE ? 0 : 0;
