@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 10
+ABI_VERSION = 11
+LN_ACT_BLOCKS = 1024   # HGNN_LN_ACT_BLOCKS
 
 
 class HgnnPlan(Structure):
@@ -78,6 +79,10 @@ _SIGNATURES = {
     "hgnn_mlp_forward_bf16": (c_int, [POINTER(HgnnMlpDesc), c_void_p, c_void_p]),
     "hgnn_mlp_supported_bf16_split": (c_int, [POINTER(HgnnMlpDesc)]),
     "hgnn_mlp_forward_bf16_split": (c_int, [POINTER(HgnnMlpDesc), c_void_p, c_void_p]),
+    "hgnn_ln_act_forward_f32": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_float,
+                                        c_void_p, c_void_p]),
+    "hgnn_ln_act_backward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32,
+                                         c_float, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

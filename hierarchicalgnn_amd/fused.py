@@ -7,8 +7,10 @@ and the width-1 classifier heads.
 Sequential with HIP row gathers + library GEMMs (still on the GPU).  The fused kernel is
 used whenever autograd is not recording: inference, and the first (no-grad) pass of every
 reentrant ``torch.utils.checkpoint`` segment -- which is how the reference runs all of its
-updates (Modules/gnn_utils.py:14-15).  When autograd records, the library path is taken;
-a differentiable variant of the fused kernel exists but is opt-in (see ``_train_enabled``).
+updates (Modules/gnn_utils.py:14-15).  When autograd records, the differentiable variant runs
+(``_FusedMLPTrain``: the same kernel dumping the pre-LayerNorm outputs, backward = HIP
+LayerNorm/activation row kernels + library GEMMs + segmented-reduce scatter); shapes it does not
+cover take the library path.
 """
 from __future__ import annotations
 
@@ -23,21 +25,20 @@ from .plan import get_index32
 
 _ACT = {nn.GELU: 1, nn.Tanh: 2, nn.ReLU: 3}
 _enabled = True
-# The differentiable variant (kernel forward + hand-written backward) is OPT-IN: measured on MI355X at
-# L=256, M=2M it is 2 % slower than autograd through the library path (112.0 vs 109.8 ms per
-# checkpointed cell step; 92.2 vs 90.5 ms without checkpointing) because the step is dominated by
-# library GEMMs either way (profiles/r01_train_step_and_hgnn_cell_L256.json).  It is kept, tested, as
-# the scaffold for an MFMA backward.
-_train_enabled = False
+# The differentiable variant (kernel forward + hand-written backward).  With ATen elementwise kernels in
+# the backward it was 2 % slower than autograd through the library path; with the one-pass HIP
+# LayerNorm/activation kernels (csrc/ln_act.hip) it is faster (L=256, M=2M cell step: 94.4 vs 110.1 ms
+# checkpointed, 75.1 vs 90.6 ms without checkpointing) and is the default when autograd records.
+_train_enabled = True
 stats = {"fused_calls": 0, "fused_train_calls": 0}
 
 
 def set_enabled(flag: bool, train: bool = None):
-    """switch the fused forward kernel off/on (A/B measurements, debugging); `train=True` also
-    opts in to the differentiable variant (off by default, see above)"""
+    """switch the fused kernels off/on (A/B measurements, debugging); `train` separately switches the
+    differentiable variant (default: follows `flag`)"""
     global _enabled, _train_enabled
     _enabled = bool(flag)
-    _train_enabled = bool(train) if train is not None else False
+    _train_enabled = bool(train) if train is not None else bool(flag)
 
 
 def _parse(net: nn.Sequential):
@@ -322,6 +323,33 @@ def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
 
 
 # --------------------------------------------------------------------------- training variant
+def _ln_act_forward(z, gamma, beta, act, eps):
+    """act(LayerNorm(z)) in one HIP pass (csrc/ln_act.hip)"""
+    out = torch.empty_like(z)
+    M, W = int(z.shape[0]), int(z.shape[1])
+    if M:
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.load().hgnn_ln_act_forward_f32(
+                _lib.ptr(z), M, W, _lib.ptr(gamma.detach().contiguous()), _lib.ptr(beta.detach().contiguous()),
+                int(act), float(eps), _lib.ptr(out), _lib.current_stream(z.device)), "hgnn_ln_act_forward_f32")
+    return out
+
+
+def _ln_act_backward(z, grad_out, gamma, beta, act, eps):
+    """(grad_z, grad_gamma, grad_beta, grad_bias) of a = act(LayerNorm(z)), z = x W^T + bias, in one HIP pass"""
+    M, W = int(z.shape[0]), int(z.shape[1])
+    dz = torch.empty_like(z)
+    partials = torch.empty((_lib.LN_ACT_BLOCKS, 3, W), dtype=torch.float32, device=z.device)
+    go = grad_out.contiguous()
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.load().hgnn_ln_act_backward_f32(
+            _lib.ptr(z), _lib.ptr(go), M, W, _lib.ptr(gamma.detach().contiguous()),
+            _lib.ptr(beta.detach().contiguous()), int(act), float(eps), _lib.ptr(dz), _lib.ptr(partials),
+            _lib.current_stream(z.device)), "hgnn_ln_act_backward_f32")
+    sums = partials.sum(dim=0)
+    return dz, sums[0], sums[1], sums[2]
+
+
 class _FusedMLPTrain(torch.autograd.Function):
     """Differentiable fused MLP.  Forward = the same MFMA kernel, additionally dumping each layer's
     pre-LayerNorm output z_l (``save_pre``).  Backward is written out by hand: LayerNorm / activation
@@ -375,36 +403,47 @@ class _FusedMLPTrain(torch.autograd.Function):
         lnb = [params[4 * l + 3] for l in range(n)]
         aten = torch.ops.aten
         g = grad_out.contiguous()
-        # re-derive y_l = LN(z_l) (+ statistics) and a_l = act(y_l): elementwise kernels only
+        hip_rows = all(int(z.shape[1]) in (64, 128, 256, 512) for z in zs)
         ys, means, rstds, outs = [], [], [], []
-        for l in range(n):
-            y, mean, rstd = torch.native_layer_norm(zs[l], [zs[l].shape[1]], lnw[l], lnb[l], ctx.eps)
-            ys.append(y)
-            means.append(mean)
-            rstds.append(rstd)
-            code = ctx.acts[l]
-            if l < n - 1 or code == 2:
-                outs.append(torch.tanh(y) if code == 2 else (torch.nn.functional.gelu(y) if code == 1
-                            else (torch.relu(y) if code == 3 else y)))
-            else:
-                outs.append(None)
+        if hip_rows:
+            # hidden activations a_l = act(LN(z_l)) for the weight gradients: one HIP pass per layer
+            outs = [_ln_act_forward(zs[l], lnw[l], lnb[l], ctx.acts[l], ctx.eps) if l < n - 1 else None
+                    for l in range(n)]
+        else:
+            # re-derive y_l = LN(z_l) (+ statistics) and a_l = act(y_l) with ATen elementwise kernels
+            for l in range(n):
+                y, mean, rstd = torch.native_layer_norm(zs[l], [zs[l].shape[1]], lnw[l], lnb[l], ctx.eps)
+                ys.append(y)
+                means.append(mean)
+                rstds.append(rstd)
+                code = ctx.acts[l]
+                if l < n - 1 or code == 2:
+                    outs.append(torch.tanh(y) if code == 2 else (torch.nn.functional.gelu(y) if code == 1
+                                else (torch.relu(y) if code == 3 else y)))
+                else:
+                    outs.append(None)
         grads_params = [None] * (4 * n)
         grads_tables = [None] * n_seg
         da = g
         for l in range(n - 1, -1, -1):
             code = ctx.acts[l]
-            if code == 1:
-                dy = aten.gelu_backward(da, ys[l], approximate="none")
-            elif code == 2:
-                dy = aten.tanh_backward(da, outs[l])
-            elif code == 3:
-                dy = da * (ys[l] > 0)
+            if hip_rows:
+                # act' -> LayerNorm backward -> dgamma / dbeta / dbias in ONE pass over (z_l, da)
+                dz, dlw, dlb, dbias = _ln_act_backward(zs[l], da, lnw[l], lnb[l], code, ctx.eps)
+                grads_params[4 * l + 1] = dbias
             else:
-                dy = da
-            dz, dlw, dlb = aten.native_layer_norm_backward(dy, zs[l], [zs[l].shape[1]], means[l], rstds[l],
-                                                           lnw[l], lnb[l], [True, True, True])
-            ys[l] = None
-            grads_params[4 * l + 1] = dz.sum(dim=0)
+                if code == 1:
+                    dy = aten.gelu_backward(da, ys[l], approximate="none")
+                elif code == 2:
+                    dy = aten.tanh_backward(da, outs[l])
+                elif code == 3:
+                    dy = da * (ys[l] > 0)
+                else:
+                    dy = da
+                dz, dlw, dlb = aten.native_layer_norm_backward(dy, zs[l], [zs[l].shape[1]], means[l], rstds[l],
+                                                               lnw[l], lnb[l], [True, True, True])
+                ys[l] = None
+                grads_params[4 * l + 1] = dz.sum(dim=0)
             grads_params[4 * l + 2] = dlw
             grads_params[4 * l + 3] = dlb
             if l > 0:

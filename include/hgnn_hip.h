@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 10
+#define HGNN_ABI_VERSION 11
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -255,6 +255,22 @@ int hgnn_mlp_forward_bf16(const hgnn_mlp_desc* d, void* out, hgnn_stream_t strea
  * Supported: K -> 2L (-> 2L) -> L, LayerNorm on every layer, every segment a multiple of 128 wide. */
 int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d);
 int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
+
+/* LayerNorm + activation of one make_mlp layer (Modules/utils.py:169-196: Linear -> LayerNorm ->
+ * act) over rows z[M, W] (the Linear's output, as dumped by hgnn_mlp_forward_f32's save_pre), one
+ * pass each -- the elementwise half of the fused MLP's backward (the GEMM half is the library's):
+ *   forward :  out[r]    = act(gamma * (z[r] - mean_r) * rstd_r + beta)
+ *   backward:  grad_z[r] = d/dz of the above applied to grad_out[r]; and per-workgroup column sums
+ *              partials[b][0][c] = sum_r grad_y * xhat (dgamma), [b][1][c] = sum_r grad_y (dbeta),
+ *              [b][2][c] = sum_r grad_z (gradient of the Linear's bias); the caller adds the
+ *              HGNN_LN_ACT_BLOCKS partial rows (deterministic, no atomics).
+ * W in {64, 128, 256, 512}; act = HGNN_ACT_*; exact-erf GELU as in the forward kernels. */
+#define HGNN_LN_ACT_BLOCKS 1024
+int hgnn_ln_act_forward_f32(const float* z, int64_t M, int32_t W, const float* gamma, const float* beta,
+                            int32_t act, float eps, float* out, hgnn_stream_t stream);
+int hgnn_ln_act_backward_f32(const float* z, const float* grad_out, int64_t M, int32_t W, const float* gamma,
+                             const float* beta, int32_t act, float eps, float* grad_z,
+                             float* partials /* [HGNN_LN_ACT_BLOCKS][3][W] */, hgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,7 @@ def train_step():
 for ckpt in (True, False):
     cell._ckpt = ckpt
     for name, fwd, trn in (("fused_fwd+fused_train", True, True), ("fused_fwd+library_bwd", True, False),
-                           ("library_only", False, False)):
+                           ("library_only", False, False)):  # noqa
         fused.set_enabled(fwd, train=trn)
         res[f"ignn_cell_fwd_bwd_{'checkpointed' if ckpt else 'no_checkpoint'}_{name}_ms"] = timeit(train_step, 3, 1)
         res[f"peak_mem_GB_{'ckpt' if ckpt else 'nockpt'}_{name}"] = torch.cuda.max_memory_allocated() / 2**30
