@@ -3,7 +3,6 @@ node partition + one halo exchange per cell reproduce the single-process result.
 The arithmetic inside each rank is the CPU oracle here (the HIP kernels need a GPU);
 what is under test is the partition bookkeeping, the exchange and its backward."""
 import os
-import socket
 import sys
 
 import pytest
@@ -19,11 +18,27 @@ HP = dict(latent=16, hidden=32, nb_edge_layer=2, nb_node_layer=3, layernorm=True
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """rendezvous token for one spawn: a fresh file path (FileStore) -- a "free" TCP port picked here can be
+    taken by someone else before the workers bind it"""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="hgnn_gloo_")
+    os.close(fd)
+    os.unlink(path)
+    _RENDEZVOUS_FILES.append(path)
+    return path
+
+
+_RENDEZVOUS_FILES = []
+
+
+@pytest.fixture(autouse=True)
+def _remove_rendezvous_files():
+    yield
+    while _RENDEZVOUS_FILES:
+        try:
+            os.unlink(_RENDEZVOUS_FILES.pop())
+        except OSError:
+            pass
 
 
 def _make_problem():
@@ -55,9 +70,7 @@ class _OracleCell:
 
 
 def _worker(rank, world, port, mode, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)
         x, ei, graph, sd, nodes, edges, r_n, r_e = _make_problem()
@@ -181,9 +194,7 @@ def _make_hproblem():
 
 
 def _hworker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)
         x, ei, graph, sd, bg, bw, sg, sw, t, r = _make_hproblem()
@@ -265,9 +276,7 @@ class _OracleIGCell:
 
 
 def _ec_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)
         x, ei, sd = _make_ec_problem()
