@@ -12,12 +12,19 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def rccl_world1():
+    import tempfile
     import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    fd, path = tempfile.mkstemp(prefix="hgnn_rccl_")   # FileStore rendezvous: no fixed TCP port to collide on
+    os.close(fd)
+    os.unlink(path)
+    dist.init_process_group("nccl", init_method=f"file://{path}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
     yield dist
     dist.destroy_process_group()
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize("mode", ["all_gather", "all_to_all"])
