@@ -213,3 +213,43 @@ def test_fused_train_backward_matches_autograd(L, layers):
     fused.set_enabled(True)
     for a, b in zip(results["fused"], results["library"]):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL
+
+
+@pytest.mark.parametrize("W", [64, 128, 256, 512])
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_ln_act_row_kernels_against_autograd(W, act):
+    """hgnn_ln_act_forward_f32 / hgnn_ln_act_backward_f32 (one make_mlp layer's LayerNorm + activation and
+    its backward incl. dgamma / dbeta / dbias column sums) against torch autograd; ragged row count"""
+    from hierarchicalgnn_amd import fused
+    g = torch.Generator().manual_seed(W + act)
+    M = 1000 + act   # not a multiple of the 16-row step
+    z = (torch.randn(M, W, generator=g) * 1.5 + 0.3).cuda()
+    gamma = (1 + 0.2 * torch.randn(W, generator=g)).cuda()
+    beta = (0.2 * torch.randn(W, generator=g)).cuda()
+    go = torch.randn(M, W, generator=g).cuda()
+    fn = {0: lambda t: t, 1: torch.nn.functional.gelu, 2: torch.tanh, 3: torch.relu}[act]
+    zr = z.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = fn(torch.nn.functional.layer_norm(zr, [W], gr, br, 1e-5))
+    ref.backward(go)
+    out = fused._ln_act_forward(z, gamma, beta, act, 1e-5)
+    assert rel_err(out.cpu().numpy(), ref.detach().cpu().numpy()) <= TOL
+    dz, dg, db, dbias = fused._ln_act_backward(z, go, gamma, beta, act, 1e-5)
+    assert rel_err(dz.cpu().numpy(), zr.grad.cpu().numpy()) <= TOL
+    assert rel_err(dg.cpu().numpy(), gr.grad.cpu().numpy()) <= TOL
+    assert rel_err(db.cpu().numpy(), br.grad.cpu().numpy()) <= TOL
+    assert rel_err(dbias.cpu().numpy(), zr.grad.sum(0).cpu().numpy(), ) <= 10 * TOL   # sums to ~0: absolute scale
+    # deterministic (per-workgroup partials, no atomics)
+    dz2, dg2, db2, dbias2 = fused._ln_act_backward(z, go, gamma, beta, act, 1e-5)
+    assert torch.equal(dz, dz2) and torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dbias, dbias2)
+
+
+def test_ln_act_row_kernels_empty_and_errors():
+    from hierarchicalgnn_amd import fused
+    z = torch.zeros(0, 128).cuda()
+    gamma, beta = torch.ones(128).cuda(), torch.zeros(128).cuda()
+    assert fused._ln_act_forward(z, gamma, beta, 1, 1e-5).shape == (0, 128)
+    dz, dg, db, dbias = fused._ln_act_backward(z, z, gamma, beta, 1, 1e-5)
+    assert dz.shape == (0, 128) and float(dg.abs().sum()) == 0.0 and float(dbias.abs().sum()) == 0.0
+    with pytest.raises(RuntimeError, match="width must be"):
+        fused._ln_act_forward(torch.zeros(4, 96).cuda(), torch.ones(96).cuda(), torch.zeros(96).cuda(), 1, 1e-5)
