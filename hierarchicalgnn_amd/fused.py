@@ -27,8 +27,9 @@ _ACT = {nn.GELU: 1, nn.Tanh: 2, nn.ReLU: 3}
 _enabled = True
 # The differentiable variant (kernel forward + hand-written backward).  With ATen elementwise kernels in
 # the backward it was 2 % slower than autograd through the library path; with the one-pass HIP
-# LayerNorm/activation kernels (csrc/ln_act.hip) it is faster (L=256, M=2M cell step: 94.4 vs 110.1 ms
-# checkpointed, 75.1 vs 90.6 ms without checkpointing) and is the default when autograd records.
+# LayerNorm/activation kernels (csrc/ln_act.hip) and the first-layer gradients factored through a
+# segment-reduced dz it is faster (L=256, M=2M cell step: 82 vs 110 ms checkpointed, 63 vs 91 ms
+# without checkpointing) and is the default when autograd records.
 _train_enabled = True
 stats = {"fused_calls": 0, "fused_train_calls": 0}
 
@@ -390,7 +391,7 @@ class _FusedMLPTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        from .ops import _seg_reduce, _spread_rows
+        from .ops import _seg_reduce
         from .plan import get_plan
         n, indices = ctx.n, ctx.indices
         n_seg = len(indices)
@@ -451,28 +452,32 @@ class _FusedMLPTrain(torch.autograd.Function):
                 da = dz @ W[l]
                 outs[l - 1] = None
             else:
-                # weight gradient of the first layer as ONE GEMM over the concatenated input rows
-                # (three N=L GEMMs picked a 256x32 tile and ran 1.7x longer); the [M,K] concat is
-                # transient and only exists during this backward
-                plans, parts = [], []
+                # First layer.  A gathered segment x_s = table[idx] enters linearly, so both of its
+                # gradients factor through S = segment_reduce(dz, idx)  ([table rows, H], one HBM pass):
+                #   dW[:, s] = dz^T table[idx] = S^T table        (K = table rows instead of M)
+                #   d table  = scatter(dz W_s, idx) = S W_s
+                # i.e. for nodes[graph[k]] the two M-row GEMMs (and the gathered copy / the [M,K]
+                # concat they would read) become two N-row GEMMs: 16x fewer FLOPs at M/N = 16.7.
+                # Only a direct segment (the edge rows themselves) keeps M-row GEMMs.
+                dW_cols = []
+                col = 0
                 for s_i in range(n_seg):
                     idx = indices[s_i]
                     tab = tables[s_i].contiguous()
-                    plan = get_plan(idx, int(tab.shape[0])) if idx is not None else None
-                    plans.append(plan)
-                    parts.append(tab if idx is None else _spread_rows(plan, tab))
-                x_cat = parts[0] if n_seg == 1 else torch.cat(parts, dim=1)
-                del parts
-                dW = dz.t() @ x_cat
-                del x_cat
-                col = 0
-                for s_i in range(n_seg):
-                    w_s = int(tables[s_i].shape[1])
-                    if ctx.needs_input_grad[3 + s_i]:
-                        drows = dz @ W[0][:, col:col + w_s]
-                        grads_tables[s_i] = drows if plans[s_i] is None else _seg_reduce(plans[s_i], drows, None, None)
+                    w_s = int(tab.shape[1])
+                    W_s = W[0][:, col:col + w_s]
+                    if idx is not None:
+                        S = _seg_reduce(get_plan(idx, int(tab.shape[0])), dz, None, None)
+                        dW_cols.append(S.t() @ tab)
+                        if ctx.needs_input_grad[3 + s_i]:
+                            grads_tables[s_i] = S @ W_s
+                        del S
+                    else:
+                        dW_cols.append(dz.t() @ tab)
+                        if ctx.needs_input_grad[3 + s_i]:
+                            grads_tables[s_i] = dz @ W_s
                     col += w_s
-                grads_params[0] = dW
+                grads_params[0] = dW_cols[0] if n_seg == 1 else torch.cat(dW_cols, dim=1)
         grad_skip = [g] if ctx.has_skip else []
         return (None, None, None, *grads_tables, *grad_skip, *grads_params)
 
