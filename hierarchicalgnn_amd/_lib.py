@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 11
+ABI_VERSION = 12
 LN_ACT_BLOCKS = 1024   # HGNN_LN_ACT_BLOCKS
 
 
@@ -46,6 +46,8 @@ class HgnnMlpDesc(Structure):
         ("w0_cols", c_int32),
         ("w_last_rows", c_int32),
         ("save_pre", c_void_p * 3),
+        ("n_pre", c_int32),
+        ("pre_table", c_void_p * 2), ("pre_index", c_void_p * 2),
     ]
 
 

@@ -53,6 +53,9 @@ struct MlpArgs {
     const float* skip;
     float* out;
     float* save_pre[3];  // optional [M, width_l] dumps of each layer's pre-LayerNorm output (training)
+    const float* pre_table[2];    // pre-projected gathered segments [rows, NT1*16] (see hgnn_mlp_desc.n_pre)
+    const int32_t* pre_index[2];
+    int n_pre;
     long long M;
     int ablate;        // DIAGNOSTIC ONLY (wrong results): 1 = skip LN/act, 2 = skip weight DMA, 4 = skip barriers
 };
@@ -274,6 +277,25 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     // ---------------- layer 1: K1 (runtime) -> NT1*16, weights through LDS, X from global
     f32x4 acc1[NT1];
     init_bias<NT1>(acc1, a.b[0], g);
+    // pre-projected gathered segments: the row's accumulators start at b + sum_s P_s[idx_s[e]]
+    // (this lane's 4 features of every 16-feature tile: 64-byte pieces of the 16 P rows per load)
+    if (a.n_pre > 0) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s < a.n_pre) {
+                const long long r = (long long)a.pre_index[s][er];
+                const float* p = a.pre_table[s] + (size_t)(r < 0 ? 0 : r) * (size_t)(NT1 * 16) + g * 4;
+#pragma unroll
+                for (int T = 0; T < NT1; ++T) {
+                    const f32x4 v = *(const f32x4*)(p + T * 16);
+                    acc1[T].x += v.x;
+                    acc1[T].y += v.y;
+                    acc1[T].z += v.z;
+                    acc1[T].w += v.w;
+                }
+            }
+        }
+    }
     __builtin_amdgcn_s_setprio(2);
     {
         constexpr int BUF = NT1 * 256;
@@ -385,6 +407,9 @@ extern "C" int hgnn_mlp_supported(const hgnn_mlp_desc* d) {
     const int n = d->n_layers;
     for (int l = 0; l < n; ++l)
         if (d->W[l] == nullptr || d->b[l] == nullptr) return 0;
+    if (d->n_pre < 0 || d->n_pre > 2) return 0;
+    for (int s = 0; s < d->n_pre; ++s)
+        if (d->pre_table[s] == nullptr || d->pre_index[s] == nullptr) return 0;
     const int h = d->width[1];
     const int o = d->width[n];
     if (n == 3 && d->width[2] != h) return 0;
@@ -451,6 +476,12 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
     a.eps = d->ln_eps;
     a.skip = d->skip;
     a.out = out;
+    a.n_pre = d->n_pre;
+    for (int s = 0; s < 2; ++s) {
+        a.pre_table[s] = s < d->n_pre ? d->pre_table[s] : nullptr;
+        a.pre_index[s] = s < d->n_pre ? d->pre_index[s] : nullptr;
+        HGNN_REQUIRE((uintptr_t)a.pre_table[s] % 16 == 0, "hgnn_mlp_forward_f32: pre_table[%d] must be 16-byte aligned", s);
+    }
     a.M = d->M;
     HGNN_REQUIRE((uintptr_t)out % 16 == 0 && (uintptr_t)a.skip % 16 == 0,
                  "hgnn_mlp_forward_f32: out/skip must be 16-byte aligned");

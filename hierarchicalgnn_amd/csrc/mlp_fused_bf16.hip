@@ -427,7 +427,7 @@ extern "C" int hgnn_mlp_supported_bf16(const hgnn_mlp_desc* d) {
     const int n = d->n_layers;
     for (int l = 0; l < n; ++l)
         if (d->W[l] == nullptr || d->b[l] == nullptr || d->ln_w[l] == nullptr || d->ln_b[l] == nullptr) return 0;
-    if (d->save_pre[0] || d->save_pre[1] || d->save_pre[2]) return 0;
+    if (d->save_pre[0] || d->save_pre[1] || d->save_pre[2] || d->n_pre != 0) return 0;
     const int h = d->width[1];
     const int o = d->width[n];
     if (n == 3 && d->width[2] != h) return 0;

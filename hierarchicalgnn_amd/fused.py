@@ -69,7 +69,32 @@ def _parse(net: nn.Sequential):
     return layers or None
 
 
-def _descriptor(net, segments, skip):
+_preproject = True
+
+
+def set_preproject(flag: bool) -> None:
+    """A/B switch: project gathered segments through their block of the first Linear before the kernel"""
+    global _preproject
+    _preproject = bool(flag)
+
+
+def _projected_segments(segments, M):
+    """which gathered segments to pre-project (hgnn_mlp_desc.n_pre): table[idx] enters the first Linear
+    linearly, W_s table[idx[e]] = (table W_s^T)[idx[e]], so a table with few rows (nodes: N = M / 16.7) is
+    projected once by an N-row GEMM and only gathered inside the kernel -- the edge network's first layer
+    keeps K = L of its 3L input columns.  At least one segment must stay in the kernel's K loop."""
+    if not _preproject or len(segments) < 2 or any(int(t.shape[1]) % 16 for t, _ in segments):
+        return []
+    cand = [i for i, (t, idx) in enumerate(segments) if idx is not None and 4 * int(t.shape[0]) <= M]
+    cand = cand[:2]
+    if len(cand) == len(segments):
+        cand = cand[:-1]
+    return cand
+
+
+def _descriptor(net, segments, skip, dry=False):
+    """(descriptor, keep-alive list, M, n_out) for hgnn_mlp_forward_f32, or None.  ``dry``: only decide
+    supportability (no projection GEMMs are run; the descriptor must not be launched)."""
     layers = _parse(net)
     if layers is None or len(layers) not in (2, 3) or not (1 <= len(segments) <= 3):
         return None
@@ -77,39 +102,65 @@ def _descriptor(net, segments, skip):
         return None
     d = _lib.HgnnMlpDesc()
     keep = []
-    d.n_seg = len(segments)
     M = None
-    for i, (table, index) in enumerate(segments):
+    for table, index in segments:
         if table.dim() != 2 or not table.is_cuda or table.dtype != torch.float32:
             return None
-        t = table if table.is_contiguous() else table.contiguous()
-        keep.append(t)
-        rows = int(index.numel()) if index is not None else int(t.shape[0])
+        rows = int(index.numel()) if index is not None else int(table.shape[0])
         if M is None:
             M = rows
         elif M != rows:
             return None
-        d.seg_table[i] = t.data_ptr()
-        d.seg_width[i] = int(t.shape[1])
+    K_full = sum(int(t.shape[1]) for t, _ in segments)
+    lin0 = layers[0][0]
+    if lin0.in_features != K_full:
+        return None
+    proj = _projected_segments(segments, M) if layers[0][1] is not None else []
+    col = 0
+    kept_cols = []
+    n_kept = n_pre = 0
+    for i, (table, index) in enumerate(segments):
+        t = table if table.is_contiguous() else table.contiguous()
+        keep.append(t)
+        w = int(t.shape[1])
+        i32 = None
         if index is not None:
             i32 = get_index32(index, int(t.shape[0]))
             keep.append(i32)
-            d.seg_index[i] = i32.data_ptr() if i32.numel() else None
+        if i in proj:
+            if dry:
+                P = t
+            else:
+                P = torch.matmul(t.detach(), lin0.weight.detach()[:, col:col + w].t())   # [rows, H]
+                keep.append(P)
+            d.pre_table[n_pre] = P.data_ptr()
+            d.pre_index[n_pre] = i32.data_ptr() if i32.numel() else None
+            n_pre += 1
         else:
-            d.seg_index[i] = None
+            d.seg_table[n_kept] = t.data_ptr()
+            d.seg_width[n_kept] = w
+            d.seg_index[n_kept] = (i32.data_ptr() if i32.numel() else None) if i32 is not None else None
+            kept_cols.append((col, col + w))
+            n_kept += 1
+        col += w
+    d.n_seg, d.n_pre = n_kept, n_pre
     n = len(layers)
     d.n_layers = n
-    K = sum(int(t.shape[1]) for t, _ in segments)
+    K = sum(c1 - c0 for c0, c1 in kept_cols)
     d.width[0] = K
     eps = None
     for l, (lin, ln, act) in enumerate(layers):
-        if lin.in_features != d.width[l]:
+        if l > 0 and lin.in_features != d.width[l]:
             return None
         params = [lin.weight, lin.bias] + ([ln.weight, ln.bias] if ln is not None else [])
         for p in params:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                 return None
         W, b = lin.weight, lin.bias
+        if l == 0 and n_pre:
+            # the kernel's K loop only sees the columns of the segments that stayed
+            W = W.detach() if dry else torch.cat([W.detach()[:, c0:c1] for c0, c1 in kept_cols], dim=1).contiguous()
+            keep.append(W)
         if l == 0 and any(int(t.shape[1]) % 16 for t, _ in segments):
             if K > 16:
                 return None
@@ -288,7 +339,7 @@ def supported(net, segments, skip) -> bool:
         if any(t.requires_grad for t in tensors):
             return False
     try:
-        desc = _descriptor(net, segments, skip)
+        desc = _descriptor(net, segments, skip, dry=True)
     except RuntimeError:
         return False
     if desc is None:
@@ -487,7 +538,7 @@ def supported_train(net, segments, skip) -> bool:
     if not _train_enabled or not torch.is_grad_enabled():
         return False
     try:
-        desc = _descriptor(net, segments, skip)
+        desc = _descriptor(net, segments, skip, dry=True)
     except RuntimeError:
         return False
     if desc is None:

@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 11
+#define HGNN_ABI_VERSION 12
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -221,6 +221,16 @@ typedef struct hgnn_mlp_desc {
     float* save_pre[3];          /* optional: [M, width[l+1]] buffers that receive layer l's output
                                   * BEFORE LayerNorm/activation (what a backward pass needs; hidden
                                   * activations are recomputed from it).  NULL = not saved.         */
+    int32_t n_pre;               /* 0..2 PRE-PROJECTED gathered segments (fp32 kernel only): a gathered
+                                  * segment table[idx] enters the first Linear linearly,
+                                  *   W_s table[idx[e]] = (table W_s^T)[idx[e]],
+                                  * so the caller may project the (few) table rows once, P_s = table W_s^T
+                                  * [rows, width[1]], leave the segment out of seg_* / W[0] / width[0], and
+                                  * hand P_s here: the kernel starts row e's accumulators at
+                                  * b + sum_s P_s[pre_index[s][e]].  For nodes[graph[k]] (N rows, M = 16.7 N
+                                  * edges) this removes 2/3 of the edge network's first-layer FLOPs.  */
+    const float* pre_table[2];   /* [rows_s, width[1]], 16-byte aligned           */
+    const int32_t* pre_index[2]; /* int32[M]                                      */
 } hgnn_mlp_desc;
 
 /* 1 if hgnn_mlp_forward_f32 has an instantiation for this descriptor (host-only check):
