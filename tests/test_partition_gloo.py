@@ -31,6 +31,18 @@ def _free_port():
 _RENDEZVOUS_FILES = []
 
 
+def _by_value(items):
+    """tensors travel through the queue as numpy arrays (pickled by value): a torch tensor is passed as a
+    shared-memory handle that the receiver can only open while the sender is still alive, and the workers
+    exit right after the put"""
+    return tuple(t.detach().numpy().copy() if isinstance(t, torch.Tensor) else t for t in items)
+
+
+def _from_value(items):
+    import numpy as np
+    return tuple(torch.from_numpy(t) if isinstance(t, np.ndarray) else t for t in items)
+
+
 @pytest.fixture(autouse=True)
 def _remove_rendezvous_files():
     yield
@@ -88,8 +100,9 @@ def _worker(rank, world, port, mode, q):
         sel = own[bg[0]]
         part = O.scatter_add(bw[sel] * nodes[bg[0][sel]], bg[1][sel], 0, 13)
         pooled = partition.allreduce_supernode_sums(part)
-        q.put((rank, shard.owned_global, shard.edge_global, out_n.detach(), out_e.detach(),
-               n_loc.grad.clone(), e_loc.grad.clone(), pooled, shard.n_halo, shard.send_splits, shard.recv_splits))
+        q.put(_by_value((rank, shard.owned_global, shard.edge_global, out_n.detach(), out_e.detach(),
+                         n_loc.grad.clone(), e_loc.grad.clone(), pooled, shard.n_halo, shard.send_splits,
+                         shard.recv_splits)))
     finally:
         dist.destroy_process_group()
 
@@ -102,7 +115,7 @@ def test_partitioned_cell_matches_single_process(world, mode):
     procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=180) for _ in range(world)]
+    results = [_from_value(q.get(timeout=180)) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -211,8 +224,8 @@ def _hworker(rank, world, port, q):
         loss = (on * r["nodes"][shard.owned_global]).sum() + (oe * r["edges"][shard.edge_global]).sum() \
             + ((osn * r["sn"]).sum() + (ose * r["se"]).sum()) / world
         loss.backward()
-        q.put((rank, shard.owned_global, shard.edge_global, on.detach(), oe.detach(), osn.detach(), ose.detach(),
-               n_loc.grad.clone(), e_loc.grad.clone(), sn.grad.clone(), se.grad.clone()))
+        q.put(_by_value((rank, shard.owned_global, shard.edge_global, on.detach(), oe.detach(), osn.detach(),
+                         ose.detach(), n_loc.grad.clone(), e_loc.grad.clone(), sn.grad.clone(), se.grad.clone())))
     finally:
         dist.destroy_process_group()
 
@@ -225,7 +238,7 @@ def test_partitioned_hierarchical_cell_matches_single_process():
     procs = [ctx.Process(target=_hworker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=180) for _ in range(world)]
+    results = [_from_value(q.get(timeout=180)) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -291,7 +304,7 @@ def _ec_worker(rank, world, port, q):
         with torch.no_grad():
             scores, ids = partition.distributed_ec_forward(node_encode, edge_encode, cells, head, shard, halo, pairs,
                                                            x[shard.owned_global])
-        q.put((rank, ids, scores))
+        q.put(_by_value((rank, ids, scores)))
     finally:
         dist.destroy_process_group()
 
@@ -304,7 +317,7 @@ def test_partitioned_ec_model_matches_single_process():
     procs = [ctx.Process(target=_ec_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=180) for _ in range(world)]
+    results = [_from_value(q.get(timeout=180)) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
