@@ -47,6 +47,9 @@ struct Args {
     const unsigned short* skip;
     unsigned short* out;
     long long M;
+    const unsigned short* pre_table[2];  // pre-projected gathered segments, bf16 [rows, width1] (hgnn_mlp_desc.n_pre)
+    const int32_t* pre_index[2];
+    int n_pre;
     int ablate;  // DIAGNOSTIC (hgnn_set_option "mlp_ablate", wrong results): 1 = weights from chunk 0 only
                  // (L1-resident), 2 = no LayerNorm / activation, 4 = only the first input panel is loaded,
                  // 8 = no per-panel barriers, 16 = B reads from chunk 0 only
@@ -346,6 +349,30 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
     // ---------------- layer 1: B = input panels
     f32x4 acc1[NT1][NJ];
     init_bias<NT1, NJ>(acc1, a.b[0] + wave * NT1 * 16 + 4 * g);
+    // pre-projected gathered segments: row e starts at b + sum_s P_s[idx_s[e]] (this lane's 4 features per tile)
+    if (a.n_pre > 0) {
+#pragma unroll
+        for (int sgm = 0; sgm < 2; ++sgm) {
+            if (sgm < a.n_pre) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    long long e = e0 + j * 16 + ei;
+                    if (e >= a.M) e = a.M - 1;
+                    const long long r = (long long)a.pre_index[sgm][e];
+                    const unsigned short* p = a.pre_table[sgm] + (size_t)(r < 0 ? 0 : r) * (size_t)(NT1 * NW * 16) +
+                                              (wave * NT1 * 16 + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < NT1; ++t) {
+                        const u16x4 v = *(const u16x4*)(p + t * 16);
+                        acc1[t][j].x += bf16_float(v[0]);
+                        acc1[t][j].y += bf16_float(v[1]);
+                        acc1[t][j].z += bf16_float(v[2]);
+                        acc1[t][j].w += bf16_float(v[3]);
+                    }
+                }
+            }
+        }
+    }
     {
         const int total = a.K1 / 32;
         const u16x8* wp = (const u16x8*)a.W[0] + (size_t)(wave * NT1) * 64 + lane;
@@ -456,7 +483,10 @@ extern "C" int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d) {
     const int n = d->n_layers;
     for (int l = 0; l < n; ++l)
         if (d->W[l] == nullptr || d->b[l] == nullptr || d->ln_w[l] == nullptr || d->ln_b[l] == nullptr) return 0;
-    if (d->save_pre[0] || d->save_pre[1] || d->save_pre[2] || d->n_pre != 0) return 0;
+    if (d->save_pre[0] || d->save_pre[1] || d->save_pre[2]) return 0;
+    if (d->n_pre < 0 || d->n_pre > 2) return 0;
+    for (int s = 0; s < d->n_pre; ++s)
+        if (d->pre_table[s] == nullptr || d->pre_index[s] == nullptr) return 0;
     if (d->M < 0 || d->M > 0x7fffffffLL) return 0;
     const int h = d->width[1];
     const int o = d->width[n];
@@ -503,6 +533,12 @@ extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hg
     a.skip = (const unsigned short*)d->skip;
     a.out = (unsigned short*)out;
     a.M = d->M;
+    a.n_pre = d->n_pre;
+    for (int s = 0; s < 2; ++s) {
+        a.pre_table[s] = s < d->n_pre ? (const unsigned short*)d->pre_table[s] : nullptr;
+        a.pre_index[s] = s < d->n_pre ? d->pre_index[s] : nullptr;
+        HGNN_REQUIRE((uintptr_t)a.pre_table[s] % 8 == 0, "hgnn_mlp_forward_bf16_split: pre_table[%d] must be 8-byte aligned", s);
+    }
     a.ablate = g_opt_mlp_ablate;
     HGNN_REQUIRE((uintptr_t)out % 8 == 0 && (uintptr_t)a.skip % 8 == 0,
                  "hgnn_mlp_forward_bf16_split: out/skip must be 8-byte aligned");

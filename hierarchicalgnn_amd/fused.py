@@ -70,6 +70,10 @@ def _parse(net: nn.Sequential):
 
 
 _preproject = True
+# bf16 split kernel: implemented and parity-tested, but measured SLOWER (L=256: 3.7 vs 2.7 ms; L=512: 9.6 vs
+# 8.6 ms): the accumulator-layout gather of bf16 P rows is 32-byte pieces issued at the start of every
+# 64-row tile, which costs more than the 2/3 of the first layer's MFMAs it saves at 16x the matrix rate.
+_preproject_bf16 = False
 
 
 def set_preproject(flag: bool) -> None:
@@ -240,9 +244,10 @@ def _wants_split(net, segments) -> bool:
     return o in (128, 256, 512) and all(w == 2 * o for w in widths[:-1])
 
 
-def _descriptor_bf16(net, segments, skip, split=False):
+def _descriptor_bf16(net, segments, skip, split=False, dry=False):
     """descriptor for hgnn_mlp_forward_bf16 (bf16 rows, bf16 slot-ordered weights, fp32 bias / LayerNorm)
-    or, with ``split``, for hgnn_mlp_forward_bf16_split (weights in A-fragment order)"""
+    or, with ``split``, for hgnn_mlp_forward_bf16_split (weights in A-fragment order; gathered segments
+    of small tables pre-projected as in the fp32 path, P_s rounded once to bf16)"""
     layers = _parse(net)
     if layers is None or len(layers) not in (2, 3) or not (1 <= len(segments) <= 3):
         return None
@@ -250,38 +255,60 @@ def _descriptor_bf16(net, segments, skip, split=False):
         return None
     d = _lib.HgnnMlpDesc()
     keep = []
-    d.n_seg = len(segments)
     M = None
-    for i, (table, index) in enumerate(segments):
+    for table, index in segments:
         if table.dim() != 2 or not table.is_cuda or table.dtype != torch.bfloat16:
             return None
-        t = table if table.is_contiguous() else table.contiguous()
-        keep.append(t)
-        rows = int(index.numel()) if index is not None else int(t.shape[0])
+        rows = int(index.numel()) if index is not None else int(table.shape[0])
         if M is None:
             M = rows
         elif M != rows:
             return None
-        d.seg_table[i] = t.data_ptr()
-        d.seg_width[i] = int(t.shape[1])
+    lin0 = layers[0][0]
+    if lin0.in_features != sum(int(t.shape[1]) for t, _ in segments) or not lin0.weight.is_cuda:
+        return None
+    proj = _projected_segments(segments, M) if (split and _preproject_bf16) else []
+    col = n_kept = n_pre = 0
+    kept_cols = []
+    for i, (table, index) in enumerate(segments):
+        t = table if table.is_contiguous() else table.contiguous()
+        keep.append(t)
+        w = int(t.shape[1])
+        i32 = None
         if index is not None:
             i32 = get_index32(index, int(t.shape[0]))
             keep.append(i32)
-            d.seg_index[i] = i32.data_ptr() if i32.numel() else None
+        if i in proj:
+            if dry:
+                P = t
+            else:
+                P = torch.matmul(t.float(), lin0.weight.detach()[:, col:col + w].float().t()).to(torch.bfloat16)
+                keep.append(P)
+            d.pre_table[n_pre] = P.data_ptr()
+            d.pre_index[n_pre] = i32.data_ptr() if i32.numel() else None
+            n_pre += 1
         else:
-            d.seg_index[i] = None
+            d.seg_table[n_kept] = t.data_ptr()
+            d.seg_width[n_kept] = w
+            d.seg_index[n_kept] = (i32.data_ptr() if i32.numel() else None) if i32 is not None else None
+            kept_cols.append((col, col + w))
+            n_kept += 1
+        col += w
+    d.n_seg, d.n_pre = n_kept, n_pre
     n = len(layers)
     d.n_layers = n
-    d.width[0] = sum(int(t.shape[1]) for t, _ in segments)
+    d.width[0] = sum(c1 - c0 for c0, c1 in kept_cols)
     eps = None
     for l, (lin, ln, act) in enumerate(layers):
-        if lin.in_features != d.width[l] or not lin.weight.is_cuda:
+        if (l > 0 and lin.in_features != d.width[l]) or not lin.weight.is_cuda:
             return None
         W = lin.weight.detach()
+        if l == 0 and n_pre and not dry:
+            W = torch.cat([W[:, c0:c1] for c0, c1 in kept_cols], dim=1)
         if split:
-            if lin.in_features % 32 or lin.out_features % 64:
+            if W.shape[1] % 32 or lin.out_features % 64:
                 return None
-            W = _fragment_order(W.to(torch.bfloat16))
+            W = W if dry else _fragment_order(W.to(torch.bfloat16).contiguous())
         else:
             if l > 0:
                 if lin.in_features % 32:
@@ -325,7 +352,7 @@ def supported(net, segments, skip) -> bool:
                 return False
         split = _wants_split(net, segments)
         try:
-            desc = _descriptor_bf16(net, segments, skip, split)
+            desc = _descriptor_bf16(net, segments, skip, split, dry=True)
         except RuntimeError:
             return False
         if desc is None:

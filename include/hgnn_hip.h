@@ -221,7 +221,7 @@ typedef struct hgnn_mlp_desc {
     float* save_pre[3];          /* optional: [M, width[l+1]] buffers that receive layer l's output
                                   * BEFORE LayerNorm/activation (what a backward pass needs; hidden
                                   * activations are recomputed from it).  NULL = not saved.         */
-    int32_t n_pre;               /* 0..2 PRE-PROJECTED gathered segments (fp32 kernel only): a gathered
+    int32_t n_pre;               /* 0..2 PRE-PROJECTED gathered segments (fp32 kernel and bf16 split kernel): a gathered
                                   * segment table[idx] enters the first Linear linearly,
                                   *   W_s table[idx[e]] = (table W_s^T)[idx[e]],
                                   * so the caller may project the (few) table rows once, P_s = table W_s^T
@@ -229,7 +229,8 @@ typedef struct hgnn_mlp_desc {
                                   * hand P_s here: the kernel starts row e's accumulators at
                                   * b + sum_s P_s[pre_index[s][e]].  For nodes[graph[k]] (N rows, M = 16.7 N
                                   * edges) this removes 2/3 of the edge network's first-layer FLOPs.  */
-    const float* pre_table[2];   /* [rows_s, width[1]], 16-byte aligned           */
+    const float* pre_table[2];   /* [rows_s, width[1]], 16-byte aligned (bf16 rows, 8-byte aligned, for
+                                  * hgnn_mlp_forward_bf16_split)                    */
     const int32_t* pre_index[2]; /* int32[M]                                      */
 } hgnn_mlp_desc;
 

@@ -79,11 +79,14 @@ def test_bf16_unsupported_width_is_an_error():
     (128, 2, 3, 300, True), (256, 2, 3, 200, True), (512, 2, 3, 131, True), (128, 3, 3, 129, True),
     (256, 3, 2, 90, True), (512, 3, 2, 70, True), (256, 2, 1, 64, True), (256, 2, 3, 1, True),
     # 128 rows x 8 waves launch shape of the same kernel (hgnn_set_option "mlp_split_shape" = 1)
-    (256, 2, 3, 333, "shape1"), (256, 2, 2, 128, "shape1"), (512, 2, 3, 131, "shape1"), (512, 3, 2, 70, "shape1")])
+    (256, 2, 3, 333, "shape1"), (256, 2, 2, 128, "shape1"), (512, 2, 3, 131, "shape1"), (512, 3, 2, 70, "shape1"),
+    # pre-projected gathered segments in the bf16 split kernel (off by default: measured slower)
+    (256, 2, 3, 2000, "preproject"), (128, 2, 3, 1500, "preproject")])
 def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M, split):
     """bf16-MFMA fused MLP: against the fp32 oracle evaluated on the bf16-rounded inputs and weights"""
     from hierarchicalgnn_amd import _lib, fused, make_mlp
     shape1 = split == "shape1"
+    fused._preproject_bf16 = split == "preproject"
     split = bool(split)
     fused.set_bf16_split(split)
     _lib.load().hgnn_set_option(b"mlp_split_shape", 1 if shape1 else 0)
@@ -114,6 +117,7 @@ def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M, split):
             out = fused.fused_concat_mlp(net, segs, segs[-1][0])
     finally:
         fused.set_bf16_split(True)
+        fused._preproject_bf16 = False
         _lib.load().hgnn_set_option(b"mlp_split_shape", -1)
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
     # hidden activations are rounded to bf16 between layers: a few bf16 ulps at the output scale
