@@ -253,3 +253,29 @@ def test_ln_act_row_kernels_empty_and_errors():
     assert dz.shape == (0, 128) and float(dg.abs().sum()) == 0.0 and float(dbias.abs().sum()) == 0.0
     with pytest.raises(RuntimeError, match="width must be"):
         fused._ln_act_forward(torch.zeros(4, 96).cuda(), torch.ones(96).cuda(), torch.zeros(96).cuda(), 1, 1e-5)
+
+
+@pytest.mark.parametrize("L,layers", [(32, 2), (64, 2), (128, 2), (256, 2), (128, 3)])
+def test_preprojected_segments_equal_the_full_k_kernel(L, layers):
+    """hgnn_mlp_desc.n_pre: projecting the gathered node segments through their block of the first Linear
+    (N-row GEMMs) and gathering the projections inside the kernel == the kernel run on all 3L columns"""
+    from hierarchicalgnn_amd import fused
+    g = torch.Generator().manual_seed(7 * L + layers)
+    net = _mk(3 * L, L, layers, "Tanh" if layers == 2 else "GELU", seed=L + 1).cuda()
+    n_tab, M = 101, 1777
+    table = torch.randn(n_tab, L, generator=g).cuda()
+    direct = torch.randn(M, L, generator=g).cuda()
+    i0 = torch.randint(0, n_tab, (M,), generator=g).cuda()
+    i1 = torch.randint(0, n_tab, (M,), generator=g).cuda()
+    segs = [(table, i0), (table, i1), (direct, None)]
+    outs = {}
+    try:
+        with torch.no_grad():
+            for on in (True, False):
+                fused.set_preproject(on)
+                d = fused._descriptor(net, segs, direct)[0]
+                assert int(d.n_pre) == (2 if on else 0) and int(d.n_seg) == (1 if on else 3)
+                outs[on] = fused.fused_concat_mlp(net, segs, direct)
+    finally:
+        fused.set_preproject(True)
+    assert rel_err(outs[True].cpu().numpy(), outs[False].cpu().numpy()) <= 1e-5
