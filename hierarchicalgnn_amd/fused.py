@@ -440,7 +440,8 @@ def _atb(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     if c < 256:
         return A.t() @ B
     main = c * chunks
-    out = torch.bmm(A[:main].view(chunks, c, A.shape[1]).transpose(1, 2), B[:main].view(chunks, c, B.shape[1])).sum(dim=0)
+    out = torch.bmm(A[:main].reshape(chunks, c, A.shape[1]).transpose(1, 2),
+                    B[:main].reshape(chunks, c, B.shape[1])).sum(dim=0)
     if main < n:
         out += A[main:].t() @ B[main:]
     return out
