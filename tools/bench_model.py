@@ -11,14 +11,15 @@ from hierarchicalgnn_amd import fused, synth
 from hierarchicalgnn_amd.models import EC_InteractionGNN
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+BF16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"   # bf16 latent rows (hparams feature_dtype), fp32 encoders / head
 torch.manual_seed(1236)
 hp = dict(spatial_channels=3, latent=L, hidden=2 * L, n_interaction_graph_iters=14, nb_node_layer=3,
           nb_edge_layer=2, output_layers=3, hidden_output_activation="GELU", hidden_activation="GELU",
-          layernorm=True, share_weight=False)
+          layernorm=True, share_weight=False, feature_dtype="bf16" if BF16 else "fp32")
 model = EC_InteractionGNN(hp).cuda().eval()
 x, ei = synth.trackml_event()
 x, ei = x.cuda(), ei.cuda()
-res = {"model": "EC-IN", "latent": L, "cells": 14, "N": x.shape[0], "E": ei.shape[1],
+res = {"model": "EC-IN", "latent": L, "feature_dtype": hp["feature_dtype"], "cells": 14, "N": x.shape[0], "E": ei.shape[1],
        "params": sum(p.numel() for p in model.parameters())}
 M = 2 * ei.shape[1]
 flop = 14 * (2 * (3 * L * 2 * L + 2 * L * L) * M + 2 * (2 * L * 2 * L + 4 * L * L + 2 * L * L) * x.shape[0])
