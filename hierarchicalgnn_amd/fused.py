@@ -135,7 +135,8 @@ def _descriptor(net, segments, skip, dry=False):
             if dry:
                 P = t
             else:
-                P = torch.matmul(t.detach(), lin0.weight.detach()[:, col:col + w].t())   # [rows, H]
+                with torch.autocast("cuda", enabled=False):   # the kernel reads P as fp32
+                    P = torch.matmul(t.detach(), lin0.weight.detach()[:, col:col + w].t())   # [rows, H]
                 keep.append(P)
             d.pre_table[n_pre] = P.data_ptr()
             d.pre_index[n_pre] = i32.data_ptr() if i32.numel() else None
@@ -282,7 +283,8 @@ def _descriptor_bf16(net, segments, skip, split=False, dry=False):
             if dry:
                 P = t
             else:
-                P = torch.matmul(t.float(), lin0.weight.detach()[:, col:col + w].float().t()).to(torch.bfloat16)
+                with torch.autocast("cuda", enabled=False):
+                    P = torch.matmul(t.float(), lin0.weight.detach()[:, col:col + w].float().t()).to(torch.bfloat16)
                 keep.append(P)
             d.pre_table[n_pre] = P.data_ptr()
             d.pre_index[n_pre] = i32.data_ptr() if i32.numel() else None
@@ -487,6 +489,11 @@ class _FusedMLPTrain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        with torch.autocast("cuda", enabled=False):   # fp32 GEMMs whatever the caller's autocast state
+            return _FusedMLPTrain._backward(ctx, grad_out.float())
+
+    @staticmethod
+    def _backward(ctx, grad_out):
         from .ops import _seg_reduce
         from .plan import get_plan
         n, indices = ctx.n, ctx.indices

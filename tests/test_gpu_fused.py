@@ -279,3 +279,29 @@ def test_preprojected_segments_equal_the_full_k_kernel(L, layers):
     finally:
         fused.set_preproject(True)
     assert rel_err(outs[True].cpu().numpy(), outs[False].cpu().numpy()) <= 1e-5
+
+
+def test_fused_paths_ignore_a_callers_autocast_region():
+    """the fused kernels read fp32 buffers: host-side GEMMs around them (segment projections, weight
+    gradients) must not follow an enclosing torch.autocast region into bf16"""
+    from hierarchicalgnn_amd import mlp
+    g = torch.Generator().manual_seed(11)
+    L, M, n_tab = 64, 900, 50
+    net = _mk(3 * L, L, 2, "Tanh", seed=3).cuda()
+    table0 = torch.randn(n_tab, L, generator=g).cuda()
+    direct0 = torch.randn(M, L, generator=g).cuda()
+    i0 = torch.randint(0, n_tab, (M,), generator=g).cuda()
+    i1 = torch.randint(0, n_tab, (M,), generator=g).cuda()
+    res = {}
+    for ac in (False, True):
+        net.zero_grad(set_to_none=True)
+        table = table0.clone().requires_grad_(True)
+        direct = direct0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+            with torch.no_grad():
+                inf = mlp.concat_mlp(net, [(table, i0), (table, i1), (direct, None)], skip=direct)
+            out = mlp.concat_mlp(net, [(table, i0), (table, i1), (direct, None)], skip=direct)
+        out.sum().backward()
+        res[ac] = [inf, out.detach(), table.grad, direct.grad] + [p.grad.clone() for p in net.parameters()]
+    for a, b in zip(res[True], res[False]):
+        assert a.dtype == torch.float32 and torch.equal(a, b)
