@@ -77,30 +77,34 @@ __device__ __forceinline__ unsigned lds_addr_of(float* p) {
 
 // start staging one chunk (16 bytes per lane and row: 4 fp32 or 8 bf16 k-values per lane group) of a
 // row-major weight matrix into `lds`: points at this wave's first piece
+// (NW = waves per workgroup: piece p of a chunk is staged by wave p % NW)
+template <int NW = 4>
 __device__ __forceinline__ WStage begin_stage_bytes(const void* W, size_t row_bytes, size_t chunk_byte_off,
                                                     float* lds, int wave, int lane) {
     WStage st;
     st.src = (const char*)W + (size_t)(wave * 16 + (lane & 15)) * row_bytes + chunk_byte_off + (lane >> 4) * 16;
     st.lds = lds_addr_of(lds) + (unsigned)wave * 1024u;
-    st.piece_stride = (unsigned)(64 * row_bytes);
+    st.piece_stride = (unsigned)(NW * 16 * row_bytes);
     return st;
 }
 
+template <int NW = 4>
 __device__ __forceinline__ WStage begin_stage(const float* W, int Kdim, int k0, float* lds, int wave, int lane) {
-    return begin_stage_bytes(W, (size_t)Kdim * sizeof(float), (size_t)k0 * sizeof(float), lds, wave, lane);
+    return begin_stage_bytes<NW>(W, (size_t)Kdim * sizeof(float), (size_t)k0 * sizeof(float), lds, wave, lane);
 }
 
+template <int NW = 4>
 __device__ __forceinline__ void stage_next(WStage& st) {
     dma_piece(st.src, st.lds);
     st.src += st.piece_stride;
-    st.lds += 4096u;  // 4 pieces further
+    st.lds += NW * 1024u;  // NW pieces further
 }
 
-// number of pieces wave `wave` owns of an NF-row chunk (pieces p = wave, wave+4, ...)
-template <int NF>
+// number of pieces wave `wave` owns of an NF-row chunk (pieces p = wave, wave+NW, ...)
+template <int NF, int NW = 4>
 __device__ __forceinline__ int pieces_of(int wave) {
     constexpr int PIECES = NF / 16;
-    return PIECES % 4 == 0 ? PIECES / 4 : (PIECES / 4 + (wave < PIECES % 4 ? 1 : 0));
+    return PIECES % NW == 0 ? PIECES / NW : (PIECES / NW + (wave < PIECES % NW ? 1 : 0));
 }
 
 }  // namespace hgnn

@@ -34,6 +34,7 @@
 
 namespace hgnn {
 
+int g_opt_mlp_f32_waves = 4;  // hgnn_set_option("mlp_f32_waves"): 4 (default) or 8 waves per workgroup (L=256 edge kernel)
 int g_opt_mlp_ablate = 0;   // set through hgnn_set_option("mlp_ablate", bits): DIAGNOSTIC, wrong results
 
 struct MlpArgs {
@@ -60,12 +61,12 @@ struct MlpArgs {
     int ablate;        // DIAGNOSTIC ONLY (wrong results): 1 = skip LN/act, 2 = skip weight DMA, 4 = skip barriers
 };
 
-template <int NF>
+template <int NF, int NW>
 __device__ __forceinline__ void stage_w(const float* __restrict__ W, int Kdim, int k0, float* lds,
                                         int wave, int lane) {
-    WStage st = begin_stage(W, Kdim, k0, lds, wave, lane);
-    const int n = pieces_of<NF>(wave);
-    for (int i = 0; i < n; ++i) stage_next(st);
+    WStage st = begin_stage<NW>(W, Kdim, k0, lds, wave, lane);
+    const int n = pieces_of<NF, NW>(wave);
+    for (int i = 0; i < n; ++i) stage_next<NW>(st);
 }
 
 // acc[T][r] (edge = lane&15, feature = 16T + 4*(lane>>4) + r): LayerNorm over features, then act
@@ -116,12 +117,12 @@ __device__ __forceinline__ void init_bias(f32x4 (&acc)[NT], const float* __restr
 // sink the reads back to their first use.  The LDS-DMA pieces that stage the NEXT chunk's weights
 // are issued one at a time BETWEEN MFMA groups (each costs the issuing wave ~60 cycles of VMEM
 // issue; in a burst ahead of the loop they were 10 % of the kernel, in the MFMA shadow they hide).
-template <int NT, int NF_NEXT>
+template <int NT, int NF_NEXT, int NW>
 __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[NT], const float* __restrict__ wb, const f32x4 b,
                                           WStage& st, int n_pieces) {
     static_assert(NT % 2 == 0, "tiles are processed in pairs");
     constexpr int PAIRS = NT / 2;
-    constexpr int PER_WAVE = (NF_NEXT / 16 + 3) / 4;
+    constexpr int PER_WAVE = (NF_NEXT / 16 + NW - 1) / NW;
     constexpr int EVERY = PAIRS >= PER_WAVE ? PAIRS / PER_WAVE : 1;
     f32x4 w0 = *(const f32x4*)(wb);
     f32x4 w1 = *(const f32x4*)(wb + 256);
@@ -135,7 +136,7 @@ __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[NT], const float* __restr
             n1 = *(const f32x4*)(wb + (T + 3) * 256);
         }
         if (((T / 2) % EVERY == 0) && issued < PER_WAVE) {
-            if (__builtin_amdgcn_readfirstlane(issued < n_pieces ? 1 : 0)) stage_next(st);  // scalar branch
+            if (__builtin_amdgcn_readfirstlane(issued < n_pieces ? 1 : 0)) stage_next<NW>(st);  // scalar branch
             ++issued;
         }
         acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, b.x, acc[T], 0, 0, 0);
@@ -151,26 +152,26 @@ __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[NT], const float* __restr
         if (T + 2 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads (next pair)
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                  // 8 MFMAs (this pair)
     }
-    for (int i = issued; i < n_pieces; ++i) stage_next(st);  // more pieces than tile pairs
+    for (int i = issued; i < n_pieces; ++i) stage_next<NW>(st);  // more pieces than tile pairs
 }
 
 // one register-resident layer: out[NTO tiles] = W[NTO*16][NTI*16] * in  (in = previous accumulators)
-template <int NTI, int NTO>
+template <int NTI, int NTO, int NW>
 __device__ __forceinline__ void dense_from_regs(const f32x4 (&in)[NTI], f32x4 (&out)[NTO],
                                                 const float* __restrict__ W, float* lds, int wave, int lane,
                                                 int ablate) {
     constexpr int KD = NTI * 16;
     constexpr int BUF = NTO * 256;  // floats per chunk buffer
-    const int n_pieces = pieces_of<NTO * 16>(wave);
+    const int n_pieces = pieces_of<NTO * 16, NW>(wave);
     __syncthreads();                // everyone is done with both buffers of the previous layer
-    stage_w<NTO * 16>(W, KD, 0, lds, wave, lane);
+    stage_w<NTO * 16, NW>(W, KD, 0, lds, wave, lane);
 #pragma unroll
     for (int c = 0; c < NTI; ++c) {
         wait_dma();                           // this wave's pieces of chunk c have landed
         if (!(ablate & 4)) __syncthreads();   // everyone's have; buffer (c+1)&1 is free again
         const float* wb = lds + (c & 1) * BUF + lane * 4;
-        WStage st = begin_stage(W, KD, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
-        mma_chunk<NTO, NTO * 16>(out, wb, in[c], st, (c + 1 < NTI && !(ablate & 2)) ? n_pieces : 0);
+        WStage st = begin_stage<NW>(W, KD, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
+        mma_chunk<NTO, NTO * 16, NW>(out, wb, in[c], st, (c + 1 < NTI && !(ablate & 2)) ? n_pieces : 0);
     }
 }
 
@@ -208,14 +209,14 @@ __device__ __forceinline__ void dump_pre(const f32x4 (&acc)[NT], float* base, lo
 // ACT_H / ACT_O: activation of the hidden layers / of the last layer (HGNN_ACT_*), or -1 = read
 // it from the descriptor per element (keeps rare combinations working without an instantiation)
 // PLAIN_LAST: the last layer has no LayerNorm / activation (classifier heads, width-1 output)
-template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, bool PLAIN_LAST = false>
-__global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
+template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, bool PLAIN_LAST = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, MINW) void k_fused_mlp(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ei = lane & 15;
     const int g = lane >> 4;
-    const long long e = (long long)blockIdx.x * 64 + wave * 16 + ei;
+    const long long e = (long long)blockIdx.x * (NW * 16) + wave * 16 + ei;
     const bool valid = e < a.M;
     const long long er = valid ? e : 0;
 
@@ -300,8 +301,8 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     {
         constexpr int BUF = NT1 * 256;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        stage_w<NT1 * 16>(a.W[0], a.K1, 0, lds, wave, lane);
-        const int n_pieces = pieces_of<NT1 * 16>(wave);
+        stage_w<NT1 * 16, NW>(a.W[0], a.K1, 0, lds, wave, lane);
+        const int n_pieces = pieces_of<NT1 * 16, NW>(wave);
         f32x4 x0 = smallk ? small_x() : next_x(zero);
         f32x4 x1 = next_x(zero);
         for (int c = 0; c < nc; ++c) {
@@ -309,8 +310,8 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
             if (!(a.ablate & 4)) __syncthreads();
             const f32x4 x2 = next_x(zero);
             const float* wb = lds + (c & 1) * BUF + lane * 4;
-            WStage st = begin_stage(a.W[0], a.K1, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
-            mma_chunk<NT1, NT1 * 16>(acc1, wb, x0, st, (c + 1 < nc && !(a.ablate & 2)) ? n_pieces : 0);
+            WStage st = begin_stage<NW>(a.W[0], a.K1, (c + 1) * 16, lds + ((c + 1) & 1) * BUF, wave, lane);
+            mma_chunk<NT1, NT1 * 16, NW>(acc1, wb, x0, st, (c + 1 < nc && !(a.ablate & 2)) ? n_pieces : 0);
             x0 = x1;
             x1 = x2;
         }
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     // ---------------- layer 2 (and 3): activations stay in registers
     f32x4 acc2[NT2];
     init_bias<NT2>(acc2, a.b[1], g);
-    dense_from_regs<NT1, NT2>(acc1, acc2, a.W[1], lds, wave, lane, a.ablate);
+    dense_from_regs<NT1, NT2, NW>(acc1, acc2, a.W[1], lds, wave, lane, a.ablate);
     __builtin_amdgcn_s_setprio(0);
     dump_pre<NT2>(acc2, a.save_pre[1], e, valid, g);
     if (!(a.ablate & 1))
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
         f32x4 acc3[NT3];
         init_bias<NT3>(acc3, a.b[2], g);
         __builtin_amdgcn_s_setprio(2);
-        dense_from_regs<NT2, NT3>(acc2, acc3, a.W[2], lds, wave, lane, a.ablate);
+        dense_from_regs<NT2, NT3, NW>(acc2, acc3, a.W[2], lds, wave, lane, a.ablate);
         __builtin_amdgcn_s_setprio(0);
         dump_pre<NT3>(acc3, a.save_pre[2], e, valid, g);
         if (!(a.ablate & 1)) layernorm_act<NT3, ACT_O, !PLAIN_LAST>(acc3, a.lnw[2], a.lnb[2], a.act[2], a.eps, g);
@@ -346,17 +347,17 @@ __global__ __launch_bounds__(256, MINW) void k_fused_mlp(const MlpArgs a) {
     }
 }
 
-template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, bool PLAIN_LAST = false>
+template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, bool PLAIN_LAST = false, int NW = 4>
 static int launch_mlp_act(const MlpArgs& a, hipStream_t s) {
     constexpr int maxnt = NT1 > NT2 ? (NT1 > NT3 ? NT1 : NT3) : (NT2 > NT3 ? NT2 : NT3);
     const size_t lds_bytes = (size_t)2 * maxnt * 256 * sizeof(float);
-    const unsigned grid = (unsigned)ceil_div(a.M, 64);
-    auto kern = k_fused_mlp<NT1, NT2, NT3, MINW, ACT_H, ACT_O, PLAIN_LAST>;
+    const unsigned grid = (unsigned)ceil_div(a.M, NW * 16);
+    auto kern = k_fused_mlp<NT1, NT2, NT3, MINW, ACT_H, ACT_O, PLAIN_LAST, NW>;
     if (lds_bytes > 64 * 1024) {
         HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
     }
-    kern<<<grid, 256, lds_bytes, s>>>(a);
+    kern<<<grid, NW * 64, lds_bytes, s>>>(a);
     HGNN_CHECK_HIP(hipGetLastError());
     return HGNN_OK;
 }
@@ -367,6 +368,12 @@ static int launch_mlp(const MlpArgs& a, hipStream_t s) {
     bool hidden_gelu = true;
     for (int l = 0; l + 1 < n; ++l) hidden_gelu = hidden_gelu && a.act[l] == HGNN_ACT_GELU;
     const int out = a.act[n - 1];
+    // A/B (hgnn_set_option "mlp_f32_waves" = 8): 8 waves = 128 rows per workgroup, one workgroup per CU --
+    // the same two waves per SIMD, half the weight staging per row
+    if constexpr (NT1 == 32 && NT3 == 0) {
+        if (g_opt_mlp_f32_waves == 8 && hidden_gelu && out == HGNN_ACT_TANH)
+            return launch_mlp_act<NT1, NT2, NT3, 1, HGNN_ACT_GELU, HGNN_ACT_TANH, false, 8>(a, s);
+    }
     if (hidden_gelu && out == HGNN_ACT_TANH) return launch_mlp_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_TANH>(a, s);
     if (hidden_gelu && out == HGNN_ACT_GELU) return launch_mlp_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_GELU>(a, s);
     return launch_mlp_act<NT1, NT2, NT3, MINW, -1, -1>(a, s);

@@ -25,6 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern int g_opt_mlp_ablate;
 extern int g_opt_mlp_split_variant;
+extern int g_opt_mlp_f32_waves;
 extern int g_opt_mlp_split_shape;
 extern int g_opt_mlp_bf16_shape;
 
@@ -496,6 +497,7 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     else if (!strcmp(name, "seg_xcd")) g_opt_seg_xcd = value;
     else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 31;
     else if (!strcmp(name, "mlp_split_variant")) g_opt_mlp_split_variant = value;
+    else if (!strcmp(name, "mlp_f32_waves")) g_opt_mlp_f32_waves = value;
     else if (!strcmp(name, "mlp_split_shape")) g_opt_mlp_split_shape = value;
     else if (!strcmp(name, "mlp_bf16_shape")) g_opt_mlp_bf16_shape = value;
     else {

@@ -105,6 +105,8 @@ int hgnn_sizeof_mlp_desc(void);
  *   "nt_loads", "nt_stores", "seg_unroll", "seg_wpb", "seg_xcd"   K1..K6 launch shape / cache policy
  *   "mlp_bf16_shape" bf16 MLP launch shape: 0 = 16 edges/wave, 2-deep weight ring; 1 (default) = 32
  *                  edges/wave, 3-deep ring for wide layers
+ *   "mlp_f32_waves" fp32 fused MLP, L=256 two-layer kernel: 4 (default) or 8 waves per workgroup (A/B:
+ *                  8 measured 3.6 % slower, bitwise equal)
  *   "mlp_split_shape" feature-split bf16 MLP: -1 (default) per shape, 0 = 4 waves x 64 rows, 1 = 8 waves
  *                  (L=256: x 128 rows; L=512: x 64 rows, the default there)
  *   "mlp_split_variant" schedule of the feature-split bf16 MLP: -1 (default) per shape, 0 counted
