@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU: HIP ops vs plain torch on the same device, many shapes.
+scatter_add (K1, weighted, gathered), the fused MLP (fp32: inference, training gradients; bf16), the
+LayerNorm/activation row kernels.  Usage: fuzz_parity.py [n_cases] [seed]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import hierarchicalgnn_amd as H
+from hierarchicalgnn_amd import fused, make_mlp, mlp
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+g = torch.Generator().manual_seed(seed)
+
+
+def ri(lo, hi):
+    return int(torch.randint(lo, hi + 1, (1,), generator=g))
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+
+
+worst = {}
+
+
+def note(name, err, tol, ctx):
+    worst[name] = max(worst.get(name, 0.0), err)
+    assert err <= tol, (name, err, tol, ctx)
+
+
+for case in range(n_cases):
+    # ---------------- scatter_add family
+    N, M, F = ri(1, 3000), ri(0, 20000), [4, 8, 12, 32, 64, 100, 128, 256, 512][ri(0, 8)]
+    skew = ri(0, 2)
+    idx = torch.randint(0, N, (M,), generator=g)
+    if skew == 1 and M:
+        idx = (idx % max(1, N // 50))            # duplicate-heavy
+    if skew == 2 and M:
+        idx = torch.sort(idx).values             # destination-sorted
+    src = torch.randn(M, F, generator=g).cuda()
+    idx_c = idx.cuda()
+    out = H.scatter_add(src, idx_c, dim=0, dim_size=N)
+    ref = torch.zeros(N, F, device="cuda").index_add_(0, idx_c, src)
+    note("scatter_add", rel(out, ref) if M else float(out.abs().sum()), 1e-5, (N, M, F, skew))
+    w = torch.rand(M, 1, generator=g).cuda()
+    out = H.scatter_add(src, idx_c, dim=0, dim_size=N, weight=w)
+    ref = torch.zeros(N, F, device="cuda").index_add_(0, idx_c, src * w)
+    note("scatter_add_weighted", rel(out, ref) if M else 0.0, 1e-5, (N, M, F, skew))
+    R = ri(1, 500)
+    table = torch.randn(R, F, generator=g).cuda()
+    gi = torch.randint(0, R, (M,), generator=g).cuda()
+    out = H.gather_scale_scatter(table, gi, idx_c, N, w)
+    ref = torch.zeros(N, F, device="cuda").index_add_(0, idx_c, table[gi] * w)
+    note("gather_scale_scatter", rel(out, ref) if M else 0.0, 1e-5, (N, M, F, R))
+
+    # ---------------- fused MLP, fp32 inference + training gradients
+    L = [32, 64, 128, 256][ri(0, 3)]
+    layers = ri(2, 3)
+    Mm = ri(1, 3000)
+    n_tab = ri(1, 400)
+    net = make_mlp(3 * L, 2 * L, L, layers, layer_norm=True, output_activation=["Tanh", "GELU"][ri(0, 1)],
+                   hidden_activation="GELU").cuda()
+    tab = torch.randn(n_tab, L, generator=g).cuda()
+    direct = torch.randn(Mm, L, generator=g).cuda()
+    i0 = torch.randint(0, n_tab, (Mm,), generator=g).cuda()
+    i1 = torch.randint(0, n_tab, (Mm,), generator=g).cuda()
+    segs = [(tab, i0), (tab, i1), (direct, None)]
+    with torch.no_grad():
+        out = mlp.concat_mlp(net, segs, skip=direct)
+        ref = net(torch.cat([tab[i0], tab[i1], direct], dim=1)) + direct
+    note("fused_mlp_f32", rel(out, ref), 1e-4, (L, layers, Mm, n_tab))
+    t1, d1 = tab.clone().requires_grad_(True), direct.clone().requires_grad_(True)
+    r = torch.randn(Mm, L, generator=g).cuda()
+    n0 = fused.stats["fused_train_calls"]
+    (mlp.concat_mlp(net, [(t1, i0), (t1, i1), (d1, None)], skip=d1) * r).sum().backward()
+    assert fused.stats["fused_train_calls"] == n0 + 1
+    got = [t1.grad, d1.grad] + [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    t2, d2 = tab.clone().requires_grad_(True), direct.clone().requires_grad_(True)
+    ((net(torch.cat([t2[i0], t2[i1], d2], dim=1)) + d2) * r).sum().backward()
+    want = [t2.grad, d2.grad] + [p.grad.clone() for p in net.parameters()]
+    for k, (a, b) in enumerate(zip(got, want)):
+        note("fused_mlp_f32_grads", rel(a, b), 2e-4, (L, layers, Mm, n_tab, k))
+
+    # ---------------- fused MLP, bf16
+    if L >= 64:
+        segs16 = [(tab.bfloat16(), i0), (tab.bfloat16(), i1), (direct.bfloat16(), None)]
+        with torch.no_grad():
+            out = mlp.concat_mlp(net, segs16, skip=segs16[2][0]).float()
+        note("fused_mlp_bf16_vs_fp32", rel(out, ref), 3e-2, (L, layers, Mm, n_tab))
+
+print("cases", n_cases, "seed", seed, "worst relative errors:", {k: f"{v:.2e}" for k, v in worst.items()})
