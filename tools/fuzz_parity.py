@@ -56,6 +56,28 @@ for case in range(n_cases):
     ref = torch.zeros(N, F, device="cuda").index_add_(0, idx_c, table[gi] * w)
     note("gather_scale_scatter", rel(out, ref) if M else 0.0, 1e-5, (N, M, F, R))
 
+    # ---------------- fixed-radius kNN (exact: compare index sets and distances) and per-edge dots
+    from hierarchicalgnn_amd.ops import edge_dot, knn_radius
+    D, K = [2, 3, 8, 12, 16][ri(0, 4)], [1, 3, 5, 10, 16][ri(0, 4)]
+    nq, npnt = ri(1, 700), ri(1, 900)
+    q = torch.randn(nq, D, generator=g).cuda()
+    pts = torch.randn(npnt, D, generator=g).cuda()
+    radius = float(torch.rand(1, generator=g)) * 3 + 0.2
+    idx_k, d2_k = knn_radius(q, pts, K, radius, return_dist2=True)
+    dd = ((q[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    dd = torch.where(dd < radius * radius, dd, torch.full_like(dd, float("inf")))
+    kk = min(K, npnt)
+    ref_d, _ = torch.topk(dd, kk, dim=1, largest=False)
+    got_d = torch.where(idx_k[:, :kk] >= 0, d2_k[:, :kk], torch.full_like(d2_k[:, :kk], float("inf")))
+    fin = torch.isfinite(ref_d)
+    assert bool((torch.isfinite(got_d) == fin).all()), ("knn count", nq, npnt, D, K, radius)
+    note("knn_dist2", float((got_d[fin] - ref_d[fin]).abs().max()) if bool(fin.any()) else 0.0, 1e-4, (nq, npnt, D, K))
+    assert bool((idx_k[:, kk:] == -1).all())
+    Bq = ri(0, 3000)
+    ai = torch.randint(0, nq, (Bq,), generator=g).cuda()
+    bi = torch.randint(0, npnt, (Bq,), generator=g).cuda()
+    note("edge_dot", rel(edge_dot(q, ai, pts, bi), (q[ai] * pts[bi]).sum(-1)) if Bq else 0.0, 1e-5, (Bq, D))
+
     # ---------------- fused MLP, fp32 inference + training gradients
     L = [32, 64, 128, 256][ri(0, 3)]
     layers = ri(2, 3)
