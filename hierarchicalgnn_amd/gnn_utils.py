@@ -18,6 +18,8 @@ gradients are being recorded (gnn_utils.py:14-15); pass
 """
 from __future__ import annotations
 
+import functools
+
 import torch
 import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
@@ -103,11 +105,12 @@ class HierarchicalGNNCell(nn.Module):
 
     # gnn_utils.py:138-145  (K3 + K4)
     def _supernode_update(self, nodes, supernodes, superedges, bipartite_graph, bipartite_edge_weights,
-                          super_graph, super_edge_weights):
+                          super_graph, super_edge_weights, node_message_reduce=None):
         node_messages = gather_scale_scatter(nodes, bipartite_graph[0], bipartite_graph[1],
                                              supernodes.shape[0], bipartite_edge_weights)
-        if self.node_message_reduce is not None:
-            node_messages = self.node_message_reduce(node_messages)
+        reduce = node_message_reduce if node_message_reduce is not None else self.node_message_reduce
+        if reduce is not None:
+            node_messages = reduce(node_messages)
         attention_messages = scatter_add(superedges, super_graph[1], dim=0, dim_size=supernodes.shape[0],
                                          weight=super_edge_weights)
         return concat_mlp(self.supernode_network,
@@ -125,8 +128,14 @@ class HierarchicalGNNCell(nn.Module):
     def edge_update(self, *a):
         return _maybe_checkpoint(self._ckpt, self._edge_update, *a)
 
-    def supernode_update(self, *a):
-        return _maybe_checkpoint(self._ckpt, self._supernode_update, *a)
+    def supernode_update(self, *a, node_message_reduce=None):
+        """``node_message_reduce`` (multi-GPU, partition.py): combines the per-shard node->supernode sums.
+        It is bound into the checkpointed function itself, so the backward-time recompute of a reentrant
+        checkpoint issues the same collective as the forward did."""
+        fn = self._supernode_update
+        if node_message_reduce is not None:
+            fn = functools.partial(self._supernode_update, node_message_reduce=node_message_reduce)
+        return _maybe_checkpoint(self._ckpt, fn, *a)
 
     def superedge_update(self, *a):
         return _maybe_checkpoint(self._ckpt, self._superedge_update, *a)

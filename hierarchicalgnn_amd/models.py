@@ -21,7 +21,7 @@ import torch.nn as nn
 from .gnn_utils import InteractionGNNCell, _maybe_checkpoint
 from .mlp import concat_mlp
 from .plan import memo
-from .utils import make_mlp
+from .utils import make_mlp, process_hparams
 
 
 def _bf16_features(hparams) -> bool:
@@ -48,6 +48,7 @@ def _dst_sorted(graph):
 class InteractionGNNBlock(nn.Module):
     def __init__(self, hparams, iterations, emb=True):
         super().__init__()
+        hparams = process_hparams(hparams)
         act, ln = hparams["hidden_activation"], hparams["layernorm"]
         self.node_encoder = make_mlp(hparams["spatial_channels"], hparams["hidden"], hparams["latent"],
                                      hparams["nb_node_layer"], output_activation=act, hidden_activation=act,
@@ -119,7 +120,8 @@ class EC_InteractionGNN(nn.Module):
 
     def __init__(self, hparams):
         super().__init__()
-        self.hparams = dict(hparams)
+        hparams = process_hparams(hparams)
+        self.hparams = hparams
         self.ignn_block = InteractionGNNBlock(hparams, hparams["n_interaction_graph_iters"], emb=False)
         self.edge_classifier = make_mlp(2 * hparams["latent"], hparams["hidden"], 1, hparams["output_layers"],
                                         layer_norm=hparams["layernorm"], output_activation=None,
@@ -151,6 +153,7 @@ class HierarchicalGNNBlock(nn.Module):
     def __init__(self, hparams):
         super().__init__()
         from .gnn_utils import HierarchicalGNNCell
+        hparams = process_hparams(hparams)
         act, ln = hparams["hidden_activation"], hparams["layernorm"]
         self.supernode_encoder = make_mlp(hparams["latent"], hparams["hidden"],
                                           hparams["latent"] - hparams["emb_dim"], hparams["nb_node_layer"],
@@ -227,7 +230,8 @@ class BC_MessagePassing(nn.Module):
 
     def __init__(self, hparams):
         super().__init__()
-        self.hparams = dict(hparams)
+        hparams = process_hparams(hparams)
+        self.hparams = hparams
         self.ignn_block = InteractionGNNBlock(hparams, hparams["n_interaction_graph_iters"], emb=True)
         self.hgnn_block = HierarchicalGNNBlock(hparams)
         self.bipartite_output_layer = make_mlp(2 * hparams["latent"], hparams["hidden"], 1,
@@ -272,6 +276,8 @@ class GraphedInference:
         scores = g(x_new)                            # same topology, new hit features: replay
 
     The topology (``edge_index``) is baked in: a new event needs a new capture (or the eager path).
+    Each call returns a fresh copy of the captured output buffer (a replay overwrites the buffer; pass
+    ``clone=False`` to get the aliased buffer itself and save the copy).
     """
 
     def __init__(self, model, x, edge_index, warmup: int = 2):
@@ -288,8 +294,12 @@ class GraphedInference:
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = model(self.x, self.edge_index)
 
-    def __call__(self, x=None):
+    def __call__(self, x=None, clone: bool = True):
         if x is not None:
             self.x.copy_(x)
         self.graph.replay()
-        return self.out
+        if not clone:
+            return self.out
+        if torch.is_tensor(self.out):
+            return self.out.clone()
+        return tuple(o.clone() if torch.is_tensor(o) else o for o in self.out)

@@ -275,6 +275,40 @@ def allreduce_supernode_sums(partial: torch.Tensor, group=None) -> torch.Tensor:
     return _AllReduceSum.apply(partial, group)
 
 
+def allreduce_gradients(params, group=None, bucket_bytes: int = 256 << 20) -> None:
+    """Sum the gradients of the REPLICATED parameters over the ranks of a node-partitioned event.
+
+    Every rank runs the same weights over its own shard (and the small replicated supernode /
+    superedge updates over identical inputs with its share of their loss terms), so after
+    ``backward`` each ``p.grad`` is a partial sum; the optimiser needs the total.  Gradients are
+    packed into few large fp32 buckets (ring all-reduce over xGMI is per-link bound: large messages,
+    few collectives) and summed in place.  A parameter without a gradient on this rank contributes
+    zeros, so every rank issues identical collectives."""
+    import torch.distributed as dist
+    params = [p for p in params if p.requires_grad]
+    if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    i = 0
+    while i < len(params):
+        j, size = i, 0
+        while j < len(params) and (j == i or (size + params[j].numel()) * 4 <= bucket_bytes):
+            size += params[j].numel()
+            j += 1
+        chunk = params[i:j]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float()
+                          for p in chunk])
+        dist.all_reduce(flat, group=group)
+        off = 0
+        for p in chunk:
+            g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += p.numel()
+        i = j
+
+
 def shard_bipartite(shard: EventShard, bipartite_graph: torch.Tensor, bipartite_edge_weights: torch.Tensor):
     """keep the bipartite edges whose hit this rank owns; hit ids become local, supernode ids
     stay global (supernodes are replicated).  Returns (graph[2,B_p], weights[B_p,1], selection)."""
@@ -290,14 +324,13 @@ def distributed_hgnn_cell_forward(cell, halo: HaloExchange, nodes_owned, edges_l
     """HierarchicalGNNCell.forward (Modules/gnn_utils.py:155-169) on one shard.  Supernodes and
     superedges are replicated (every rank computes their small updates redundantly); the only
     collectives are the all_reduce of the node->supernode sums and the halo exchange before the
-    edge update.  Gradients of the replicated parameters must be summed over ranks (as DDP does)."""
-    prev = getattr(cell, "node_message_reduce", None)
-    cell.node_message_reduce = lambda t: allreduce_supernode_sums(t, group)
-    try:
-        supernodes = cell.supernode_update(nodes_owned, supernodes, superedges, bipartite_local,
-                                           bipartite_w_local, super_graph, super_w)
-    finally:
-        cell.node_message_reduce = prev
+    edge update.  The reduce is handed to ``supernode_update`` as an argument (not installed and removed
+    around the call): under the cell's reentrant checkpoint the backward re-runs the update, and the
+    recompute must issue the same all_reduce.  Gradients of the replicated parameters are partial sums
+    on every rank: ``allreduce_gradients`` combines them after backward."""
+    supernodes = cell.supernode_update(nodes_owned, supernodes, superedges, bipartite_local,
+                                       bipartite_w_local, super_graph, super_w,
+                                       node_message_reduce=lambda t: allreduce_supernode_sums(t, group))
     nodes_owned = cell.node_update(nodes_owned, edges_local, supernodes, local_graph, bipartite_local,
                                    bipartite_w_local)
     superedges = cell.superedge_update(supernodes, superedges, super_graph, super_w)

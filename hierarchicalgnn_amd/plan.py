@@ -126,7 +126,10 @@ class GraphPlan:
 def _key(t: Optional[torch.Tensor]):
     if t is None:
         return None
-    return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.device.index)
+    # inference tensors (created under torch.inference_mode(), as the reference runs its models) do
+    # not track a version counter -- and cannot be edited in place outside inference mode either
+    version = 0 if t.is_inference() else t._version
+    return (t.data_ptr(), version, tuple(t.shape), tuple(t.stride()), t.device.index)
 
 
 def get_plan(dst_index: torch.Tensor, dim_size: int, gather_index: Optional[torch.Tensor] = None,

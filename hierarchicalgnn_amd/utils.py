@@ -30,3 +30,20 @@ def make_mlp(input_size, hidden_size, output_size, hidden_layers, hidden_activat
             layers.append(nn.LayerNorm(sizes[-1]))
         layers.append(out_act())
     return nn.Sequential(*layers)
+
+
+def process_hparams(hparams):
+    """The reference's config contract (Modules/training_utils.py:13-20): its shipped YAMLs carry
+    ``hidden: ratio`` + ``hidden_ratio`` (EdgeClassifier/Configs/IN.yaml:35-36,
+    BipartiteClassification/Configs/HGNN_GMM.yaml), resolved to ``hidden_ratio * latent`` before the
+    model is built, and ``cluster_granularity`` defaults to 0.  Returns a resolved COPY; the model
+    mirrors call this in their constructors, so a raw YAML dict drops in."""
+    hp = dict(hparams)
+    if hp.get("hidden") == "ratio":
+        if "hidden_ratio" not in hp:
+            raise KeyError("hparams['hidden'] == 'ratio' needs hparams['hidden_ratio'] (training_utils.py:14-15)")
+        hp["hidden"] = int(hp["hidden_ratio"] * hp["latent"])
+    elif isinstance(hp.get("hidden"), str):
+        raise ValueError(f"hparams['hidden'] must be an int or 'ratio', got {hp['hidden']!r}")
+    hp.setdefault("cluster_granularity", 0)
+    return hp

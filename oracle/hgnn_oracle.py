@@ -170,6 +170,48 @@ def ec_in_forward(sd, hp, x, graph):
 
 
 # ---------------------------------------------------------------------------
+# BC-HGNN-GMM message passing  [BipartiteClassification/Models/HGNN_GMM.py:86-99, :269-284, :342-344]
+# The hierarchy decision (GMM cut, connected components, kNN graphs: :244-260) is an INPUT here:
+# it is third-party library behaviour (sklearn / cugraph / frnn); the arithmetic on its result is restated.
+# ---------------------------------------------------------------------------
+def bc_ignn_block(sd, hp, x, directed):
+    """HGNN_GMM.py:86-99: (embeddings, nodes, edges)"""
+    act, ln = hp["hidden_activation"], hp["layernorm"]
+    nodes = mlp_apply(sd, "ignn_block.node_encoder.", x, hp["nb_node_layer"], act, act, ln)
+    edges = mlp_apply(sd, "ignn_block.edge_encoder.", torch.cat([x[directed[0]], x[directed[1]]], dim=1),
+                      hp["nb_edge_layer"], act, act, ln)
+    for i in range(hp["n_interaction_graph_iters"]):
+        nodes, edges = ignn_cell(sd, f"ignn_block.ignn_cells.{i}.", hp, nodes, edges, directed)
+    emb = mlp_apply(sd, "ignn_block.output_layer.", nodes, hp["output_layers"], hp["hidden_output_activation"],
+                    None, ln)
+    return F.normalize(emb), nodes, edges
+
+
+def bc_hgnn_block(sd, hp, nodes, edges, directed, means, bg, bw, sg, sw):
+    """HGNN_GMM.py:269-284 given the hierarchy: (nodes, supernodes, supernodes entering cell 0,
+    superedges entering cell 0)"""
+    act, ln = hp["hidden_activation"], hp["layernorm"]
+    pooled = supernode_pool(nodes, bg, bw, means.shape[0])                                        # :269
+    supernodes = torch.cat([means, mlp_apply(sd, "hgnn_block.supernode_encoder.", pooled, hp["nb_node_layer"],
+                                             act, act, ln)], dim=-1)                              # :270
+    superedges = mlp_apply(sd, "hgnn_block.superedge_encoder.",
+                           torch.cat([supernodes[sg[0]], supernodes[sg[1]]], dim=1), hp["nb_edge_layer"],
+                           act, act, ln)                                                          # :271
+    sn0, se0 = supernodes, superedges
+    for i in range(hp["n_hierarchical_graph_iters"]):                                             # :275-284
+        nodes, edges, supernodes, superedges = hgnn_cell(sd, f"hgnn_block.hgnn_cells.{i}.", hp, nodes, edges,
+                                                         supernodes, superedges, directed, bg, bw, sg, sw)
+    return nodes, supernodes, sn0, se0
+
+
+def bc_scores(sd, hp, nodes, supernodes, bg):
+    """HGNN_GMM.py:342-344"""
+    s = mlp_apply(sd, "bipartite_output_layer.", torch.cat([nodes[bg[0]], supernodes[bg[1]]], dim=1),
+                  hp["output_layers"], hp["hidden_output_activation"], None, hp["layernorm"])
+    return torch.sigmoid(s).squeeze()
+
+
+# ---------------------------------------------------------------------------
 # reference CPU aggregation, as timed for the cpu_baseline (BASELINE.md section 4)
 # ---------------------------------------------------------------------------
 def scatter_add_cpu_timed(src: Tensor, index: Tensor, dim_size: int, reps: int = 3):

@@ -40,3 +40,24 @@ def rel_err(a, b):
     if a.size == 0:
         return 0.0
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def elem_err(a, b):
+    """element-wise counterpart of rel_err: max over elements of |a-b| / (|b| + rms(b)).  rel_err divides
+    every difference by the LARGEST reference magnitude (normwise); this one divides by the element's own
+    magnitude plus the tensor's typical magnitude, so small elements are held to the bar as well."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    rms = max(float(np.sqrt(np.mean(b * b))), 1e-30)
+    return float((np.abs(a - b) / (np.abs(b) + rms)).max())
+
+
+def assert_parity(a, b, tol=1e-4, what=""):
+    """the fp32 parity bar, normwise AND element-wise"""
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+    b = b.detach().cpu().numpy() if hasattr(b, "detach") else np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    r, e = rel_err(a, b), elem_err(a, b)
+    assert r <= tol and e <= tol, f"{what}: normwise {r:.3g}, element-wise {e:.3g} > {tol:g}"

@@ -507,10 +507,167 @@ def gen_dataset(utils):
     print("dataset_masking.npz", len(cases), "cases")
 
 
+# --------------------------------------------------------------------------
+# Model-level fixtures at the latents BASELINE.json names (128 / 256 / 512).  Weights are a pure
+# function of (parameter name, seed) -- tests/golden/seeded.py -- so only inputs, outputs and
+# per-parameter checksums are stored.
+# --------------------------------------------------------------------------
+sys.path.insert(0, OUT)
+import seeded  # noqa: E402
+
+
+def ref_config(relpath):
+    """the reference's own YAML (data), resolved the way Modules/training_utils.py:13-20 does
+    (training_utils itself cannot be imported: it pulls in cuml)"""
+    import yaml
+    with open(os.path.join(REF, "Modules", relpath)) as f:
+        hp = yaml.safe_load(f)
+    raw = dict(hp)
+    if hp["hidden"] == "ratio":
+        hp["hidden"] = hp["hidden_ratio"] * hp["latent"]
+    hp.setdefault("cluster_granularity", 0)
+    return raw, hp
+
+
+def gen_ref_configs():
+    """the hyper-parameter dictionaries of the two configs BASELINE.json names, as parsed data (JSON):
+    what 'existing configs drop in' is tested against on the CPU"""
+    import json
+    out = {}
+    for key, rel in (("EC-IN", "EdgeClassifier/Configs/IN.yaml"),
+                     ("BC-HGNN-GMM", "BipartiteClassification/Configs/HGNN_GMM.yaml")):
+        raw, hp = ref_config(rel)
+        out[key] = {"raw": raw, "resolved_hidden": hp["hidden"]}
+    # parameter counts of the reference's own classes built from those configs
+    return out
+
+
+def gen_ec_in_config(EC, configs):
+    """BASELINE config 2: EC-IN exactly as EdgeClassifier/Configs/IN.yaml builds it (latent 128, hidden
+    256, 14 cells, 4,441,089 parameters); forward + backward of the reference's own class."""
+    _, hp = ref_config("EdgeClassifier/Configs/IN.yaml")
+    model = EC(hp)
+    seeded.fill_parameters(model, 128)
+    g = torch.Generator().manual_seed(1281)
+    x, graph = synth_event(1500, 9000, g)
+    x = x.clone()
+    scores = model(x, graph)              # the reference sets x.requires_grad = True itself (IN.py:120)
+    r = seeded.randn(128, "r_scores", scores.shape[0])
+    (scores * r).sum().backward()
+    n_params = sum(p.numel() for p in model.parameters())
+    configs["EC-IN"]["n_params"] = int(n_params)
+    d = dict(x=x.detach().numpy(), edge_index=graph.numpy(), scores=scores.detach().numpy(),
+             r_scores=r.numpy(), grad_x=x.grad.numpy(), n_params=np.int64(n_params),
+             param_checksums=seeded.checksums(model.named_parameters()),
+             grad_sketch=seeded.grad_sketch((n, p.grad) for n, p in model.named_parameters()),
+             seed=np.int64(128))
+    np.savez_compressed(os.path.join(OUT, "ec_in_L128.npz"), **d)
+    print("ec_in_L128.npz params", n_params, "edges", graph.shape[1])
+
+
+def gen_hgnn_cell_seeded(gnn_utils, latent=256, seed=256):
+    """one HierarchicalGNNCell at BASELINE config 3's width: forward + every gradient"""
+    g = torch.Generator().manual_seed(seed)
+    hp = dict(latent=latent, hidden=2 * latent, nb_edge_layer=2, nb_node_layer=3,
+              layernorm=True, hidden_activation="GELU")
+    cell = gnn_utils.HierarchicalGNNCell(hp)
+    seeded.fill_parameters(cell, seed)
+    n_nodes, n_super = 120, 11
+    _, graph = synth_event(n_nodes, 420, g)
+    graph = torch.cat([graph, graph.flip(0)], 1)
+    bg, bw, sg, sw = _bip(n_nodes, n_super, 5, 4, g)
+    bw.requires_grad_(True)
+    sw.requires_grad_(True)
+    shapes = dict(nodes=(n_nodes, latent), edges=(graph.shape[1], latent), supernodes=(n_super, latent),
+                  superedges=(sg.shape[1], latent))
+    ins = {k: seeded.randn(seed, "in." + k, *v).requires_grad_(True) for k, v in shapes.items()}
+    rs = {k: seeded.randn(seed, "r." + k, *v) for k, v in shapes.items()}
+    outs = cell(ins["nodes"], ins["edges"], ins["supernodes"], ins["superedges"], graph, bg, bw, sg, sw)
+    names = ("nodes", "edges", "supernodes", "superedges")
+    sum((o * rs[k]).sum() for k, o in zip(names, outs)).backward()
+    d = dict(graph=graph.numpy(), bipartite_graph=bg.numpy(), bipartite_edge_weights=bw.detach().numpy(),
+             super_graph=sg.numpy(), super_edge_weights=sw.detach().numpy(), latent=np.int64(latent),
+             seed=np.int64(seed), param_checksums=seeded.checksums(cell.named_parameters()),
+             grad_sketch=seeded.grad_sketch((n, p.grad) for n, p in cell.named_parameters()),
+             grad_bipartite_edge_weights=bw.grad.numpy(), grad_super_edge_weights=sw.grad.numpy())
+    for k, o in zip(names, outs):
+        d["out_" + k] = o.detach().numpy()
+        d["grad_" + k] = ins[k].grad.numpy()
+    # two full weight gradients (the widest GEMMs), the rest is pinned by the sketch
+    for k in ("edge_network.0.weight", "supernode_network.3.weight"):
+        d["grad." + k] = dict(cell.named_parameters())[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, f"hgnn_cell_L{latent}.npz"), **d)
+    print(f"hgnn_cell_L{latent}.npz")
+
+
+def gen_bc_hgnn_config(BC, latent, configs=None):
+    """BASELINE config 3 (latent 256) / the fp32 reference of config 4 (latent 512): BC-HGNN-GMM as
+    BipartiteClassification/Configs/HGNN_GMM.yaml builds it (6 + 6 cells; 25,299,957 parameters at
+    latent 256), full forward of the reference's own class; the hierarchy its stand-in clustering /
+    kNN led to is captured with the tensors entering the first HierarchicalGNNCell."""
+    _, hp = ref_config("BipartiteClassification/Configs/HGNN_GMM.yaml")
+    if latent != hp["latent"]:
+        hp["latent"] = latent
+        hp["hidden"] = hp["hidden_ratio"] * latent
+    torch.manual_seed(latent)
+    np.random.seed(latent)
+    model = BC(hp)
+    seeded.fill_parameters(model, latent)
+    model.eval()
+    model.hgnn_block.super_graph_construction.knn_radius.fill_(2.0)
+    model.hgnn_block.bipartite_graph_construction.knn_radius.fill_(2.0)
+    g = torch.Generator().manual_seed(latent + 1)
+    x, graph = synth_tracks(60, 9, g)
+    calls = []
+    cells = model.hgnn_block.hgnn_cells
+    cells[0].register_forward_hook(lambda m, inp, out: calls.append(("first", [t.detach().clone() for t in inp])))
+    cells[len(cells) - 1].register_forward_hook(
+        lambda m, inp, out: calls.append(("last", [t.detach().clone() for t in out])))
+    with torch.no_grad():
+        bg, bscores, emb = model(x.clone(), graph)
+    first = [c for c in calls if c[0] == "first"][0][1]
+    last = [c for c in calls if c[0] == "last"][0][1]
+    names = ["nodes", "edges", "supernodes", "superedges", "graph", "bipartite_graph",
+             "bipartite_edge_weights", "super_graph", "super_edge_weights"]
+    n_params = sum(p.numel() for p in model.parameters())
+    d = dict(x=x.numpy(), edge_index=graph.numpy(), bipartite_graph=bg.numpy(),
+             bipartite_scores=bscores.numpy(), embeddings=emb.numpy(), n_params=np.int64(n_params),
+             param_checksums=seeded.checksums(model.named_parameters()), seed=np.int64(latent),
+             latent=np.int64(latent))
+    for nm, t in zip(names, first):
+        if nm == "edges":                 # [2E, latent]: every 4th row pins it
+            d["cell0.in.edges_rows"] = np.arange(0, t.shape[0], 4)
+            d["cell0.in.edges_sub"] = t[::4].numpy()
+        elif nm != "graph":
+            d[f"cell0.in.{nm}"] = t.numpy()
+    d["last.out.nodes"] = last[0].numpy()
+    d["last.out.supernodes"] = last[2].numpy()
+    np.savez_compressed(os.path.join(OUT, f"bc_hgnn_L{latent}.npz"), **d)
+    if configs is not None and latent == 256:
+        configs["BC-HGNN-GMM"]["n_params"] = int(n_params)
+    print(f"bc_hgnn_L{latent}.npz params", n_params, "supernodes", first[2].shape[0], "bipartite edges",
+          bg.shape[1], "super edges", first[7].shape[1])
+
+
+def gen_large(gnn_utils, EC, BC):
+    import json
+    configs = gen_ref_configs()
+    gen_ec_in_config(EC, configs)
+    gen_hgnn_cell_seeded(gnn_utils, 256)
+    gen_bc_hgnn_config(BC, 256, configs)
+    gen_bc_hgnn_config(BC, 512)
+    with open(os.path.join(OUT, "ref_configs.json"), "w") as f:
+        json.dump(configs, f, indent=1, sort_keys=True)
+    print("ref_configs.json")
+
+
 if __name__ == "__main__":
     gnn_utils, utils, EC, BC = _import_reference()
     if "--only-dataset" in sys.argv:
         gen_dataset(utils)
+        sys.exit(0)
+    if "--only-large" in sys.argv:
+        gen_large(gnn_utils, EC, BC)
         sys.exit(0)
     gen_k1_cases()
     gen_pool()
@@ -521,3 +678,4 @@ if __name__ == "__main__":
     gen_ec_in(EC, 32)
     gen_bc_hgnn(BC, 32)
     gen_dataset(utils)
+    gen_large(gnn_utils, EC, BC)

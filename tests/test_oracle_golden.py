@@ -118,3 +118,117 @@ def test_bc_hgnn_call_sites_and_cells():
         outs = O.hgnn_cell(sd, f"hgnn_block.hgnn_cells.{i}.", hp, *args)
         for nm, o in zip(names[:4], outs):
             assert rel_err(o.numpy(), z[f"cell{i}.out.{nm}"]) <= TOL, (i, nm)
+
+
+# ---------------------------------------------------------------- configs BASELINE.json names (latent 128 / 256 / 512)
+import json
+import os
+
+import conftest
+from golden import seeded  # tests/golden/seeded.py: weights as a function of (name, seed)
+
+
+def _ref_configs():
+    with open(os.path.join(conftest.GOLDEN, "ref_configs.json")) as f:
+        return json.load(f)
+
+
+def _seeded_model(cls, raw_hparams, z):
+    model = cls(raw_hparams)
+    seeded.fill_parameters(model, int(z["seed"]))
+    seeded.check_parameters(model, z["param_checksums"])
+    return model
+
+
+def test_reference_yaml_configs_drop_in():
+    """the reference's shipped YAMLs carry ``hidden: ratio`` (EdgeClassifier/Configs/IN.yaml:35-36,
+    resolved by training_utils.py:13-15): the mirrors accept the raw dictionaries and build the reference's
+    parameter counts"""
+    from hierarchicalgnn_amd.models import BC_MessagePassing, EC_InteractionGNN
+    cfg = _ref_configs()
+    assert cfg["EC-IN"]["raw"]["hidden"] == "ratio" and cfg["BC-HGNN-GMM"]["raw"]["hidden"] == "ratio"
+    with torch.device("meta"):
+        ec = EC_InteractionGNN(cfg["EC-IN"]["raw"])
+        bc = BC_MessagePassing(cfg["BC-HGNN-GMM"]["raw"])
+    assert sum(p.numel() for p in ec.parameters()) == cfg["EC-IN"]["n_params"] == 4441089
+    assert sum(p.numel() for p in bc.parameters()) == cfg["BC-HGNN-GMM"]["n_params"] == 25299957
+    assert ec.hparams["hidden"] == cfg["EC-IN"]["resolved_hidden"] == 256
+    assert bc.hparams["hidden"] == cfg["BC-HGNN-GMM"]["resolved_hidden"] == 512
+    assert bc.hparams["cluster_granularity"] == 5
+    with pytest.raises(KeyError):
+        EC_InteractionGNN({k: v for k, v in cfg["EC-IN"]["raw"].items() if k != "hidden_ratio"})
+
+
+def test_ec_in_config2_oracle_forward_and_input_gradient():
+    """BASELINE config 2 (IN.yaml: latent 128, 14 cells): oracle == the reference's own class"""
+    from hierarchicalgnn_amd.models import EC_InteractionGNN
+    from hierarchicalgnn_amd.utils import process_hparams
+    z = load_golden("ec_in_L128.npz")
+    raw = _ref_configs()["EC-IN"]["raw"]
+    model = _seeded_model(EC_InteractionGNN, raw, z)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    scores = O.ec_in_forward(sd, process_hparams(raw), x, torch.from_numpy(z["edge_index"]))
+    assert np.abs(scores.detach().numpy() - z["scores"]).max() <= 5e-6
+    (scores * torch.from_numpy(z["r_scores"])).sum().backward()
+    assert rel_err(x.grad.numpy(), z["grad_x"]) <= 2e-5
+
+
+def test_hgnn_cell_config3_width_oracle():
+    from hierarchicalgnn_amd import HierarchicalGNNCell
+    z = load_golden("hgnn_cell_L256.npz")
+    L, seed = int(z["latent"]), int(z["seed"])
+    cell = HierarchicalGNNCell(_hp(L))
+    seeded.fill_parameters(cell, seed)
+    seeded.check_parameters(cell, z["param_checksums"])
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in cell.state_dict().items()}
+    names = ("nodes", "edges", "supernodes", "superedges")
+    t = {k: seeded.randn(seed, "in." + k, *z["out_" + k].shape).requires_grad_(True) for k in names}
+    bw = torch.from_numpy(z["bipartite_edge_weights"]).requires_grad_(True)
+    sw = torch.from_numpy(z["super_edge_weights"]).requires_grad_(True)
+    outs = O.hgnn_cell(sd, "", _hp(L), t["nodes"], t["edges"], t["supernodes"], t["superedges"],
+                       torch.from_numpy(z["graph"]), torch.from_numpy(z["bipartite_graph"]), bw,
+                       torch.from_numpy(z["super_graph"]), sw)
+    for nm, o in zip(names, outs):
+        assert rel_err(o.detach().numpy(), z["out_" + nm]) <= TOL, nm
+    sum((o * seeded.randn(seed, "r." + nm, *o.shape)).sum() for nm, o in zip(names, outs)).backward()
+    for nm in names:
+        assert rel_err(t[nm].grad.numpy(), z["grad_" + nm]) <= 1e-5, nm
+    assert rel_err(bw.grad.numpy(), z["grad_bipartite_edge_weights"]) <= 1e-5
+    assert rel_err(sw.grad.numpy(), z["grad_super_edge_weights"]) <= 1e-5
+    for k in ("edge_network.0.weight", "supernode_network.3.weight"):
+        assert rel_err(sd[k].grad.numpy(), z["grad." + k]) <= 1e-5, k
+    sk = seeded.grad_sketch((k, v.grad) for k, v in sd.items())
+    assert np.abs(sk - z["grad_sketch"]).max() <= 1e-4 * np.abs(z["grad_sketch"]).max()
+
+
+@pytest.mark.parametrize("latent", [256, 512])
+def test_bc_hgnn_config3_and_config4_reference_oracle(latent):
+    """BASELINE config 3 (HGNN_GMM.yaml: latent 256, 6 + 6 cells) and the fp32 reference of config 4
+    (latent 512): the oracle's message passing on the captured hierarchy == the reference's forward"""
+    from hierarchicalgnn_amd.models import BC_MessagePassing
+    from hierarchicalgnn_amd.utils import process_hparams
+    z = load_golden(f"bc_hgnn_L{latent}.npz")
+    raw = dict(_ref_configs()["BC-HGNN-GMM"]["raw"], latent=latent)
+    hp = process_hparams(raw)
+    model = _seeded_model(BC_MessagePassing, raw, z)
+    assert sum(p.numel() for p in model.parameters()) == int(z["n_params"])
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    x, graph = torch.from_numpy(z["x"]), torch.from_numpy(z["edge_index"])
+    directed = torch.cat([graph, graph.flip(0)], dim=1)
+    with torch.no_grad():
+        emb, nodes, edges = O.bc_ignn_block(sd, hp, x, directed)
+        assert rel_err(emb.numpy(), z["embeddings"]) <= 1e-5
+        assert rel_err(nodes.numpy(), z["cell0.in.nodes"]) <= 1e-5
+        assert rel_err(edges[torch.from_numpy(z["cell0.in.edges_rows"])].numpy(), z["cell0.in.edges_sub"]) <= 1e-5
+        t = lambda k: torch.from_numpy(z[k])
+        means = t("cell0.in.supernodes")[:, :hp["emb_dim"]]
+        n_out, sn_out, sn0, se0 = O.bc_hgnn_block(sd, hp, nodes, edges, directed, means,
+                                                  t("cell0.in.bipartite_graph"), t("cell0.in.bipartite_edge_weights"),
+                                                  t("cell0.in.super_graph"), t("cell0.in.super_edge_weights"))
+        assert rel_err(sn0.numpy(), z["cell0.in.supernodes"]) <= 1e-5
+        assert rel_err(se0.numpy(), z["cell0.in.superedges"]) <= 1e-5
+        assert rel_err(n_out.numpy(), z["last.out.nodes"]) <= 2e-5
+        assert rel_err(sn_out.numpy(), z["last.out.supernodes"]) <= 2e-5
+        scores = O.bc_scores(sd, hp, n_out, sn_out, t("bipartite_graph"))
+        assert np.abs(scores.numpy() - z["bipartite_scores"]).max() <= 2e-5

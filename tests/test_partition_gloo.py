@@ -171,10 +171,11 @@ class _OracleHCell:
         self.sd = sd
         self.node_message_reduce = None
 
-    def supernode_update(self, nodes, supernodes, superedges, bg, bw, sg, sw):
+    def supernode_update(self, nodes, supernodes, superedges, bg, bw, sg, sw, node_message_reduce=None):
         node_msg = O.scatter_add(bw * nodes[bg[0]], bg[1], 0, supernodes.shape[0])
-        if self.node_message_reduce is not None:
-            node_msg = self.node_message_reduce(node_msg)
+        reduce = node_message_reduce or self.node_message_reduce
+        if reduce is not None:
+            node_msg = reduce(node_msg)
         attn = O.scatter_add(superedges * sw, sg[1], 0, supernodes.shape[0])
         inp = torch.cat([supernodes, attn, node_msg], -1)
         return O.mlp_apply(self.sd, "supernode_network.", inp, 3, "GELU", "GELU", True) + supernodes
@@ -206,11 +207,38 @@ def _make_hproblem():
     return x, ei, graph, sd, bg, bw, sg, sw, t, r
 
 
-def _hworker(rank, world, port, q):
+def _real_cell_on_cpu(sd):
+    """The REAL HierarchicalGNNCell class (its update order, its reentrant checkpoints, its reduce
+    argument) with the three kernel entry points it calls replaced by the CPU oracle's arithmetic --
+    the HIP kernels need a GPU; what is under test is the cell/partition logic around them."""
+    from hierarchicalgnn_amd import HierarchicalGNNCell, gnn_utils
+
+    def scatter_add(src, index, dim=0, dim_size=None, weight=None):
+        return O.scatter_add(src if weight is None else src * weight, index, dim, dim_size)
+
+    def gather_scale_scatter(X, gather_index, dst_index, dim_size, weight=None, row_scale=None):
+        rows = X[gather_index]
+        if weight is not None:
+            rows = rows * weight
+        return O.scatter_add(rows, dst_index, 0, dim_size)
+
+    def concat_mlp(net, segments, skip=None, bf16_tail=False):
+        y = net(torch.cat([t if i is None else t[i] for t, i in segments], dim=-1))
+        return y if skip is None else y + skip
+
+    gnn_utils.scatter_add, gnn_utils.gather_scale_scatter, gnn_utils.concat_mlp = \
+        scatter_add, gather_scale_scatter, concat_mlp
+    cell = HierarchicalGNNCell(dict(HP, checkpointing=True))
+    cell.load_state_dict(sd)
+    return cell
+
+
+def _hworker(rank, world, port, q, real_cell=False):
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)
         x, ei, graph, sd, bg, bw, sg, sw, t, r = _make_hproblem()
+        cell = _real_cell_on_cpu(sd) if real_cell else _OracleHCell(sd)
         shard = partition.partition_event(x, ei, world, rank)
         halo = partition.HaloExchange(shard, "cpu", mode="all_to_all")
         bgl, bwl, bsel = partition.shard_bipartite(shard, bg, bw)
@@ -219,23 +247,34 @@ def _hworker(rank, world, port, q):
         sn = t["sn"].clone().requires_grad_(True)
         se = t["se"].clone().requires_grad_(True)
         on, oe, osn, ose = partition.distributed_hgnn_cell_forward(
-            _OracleHCell(sd), halo, n_loc, e_loc, sn, se, shard.local_graph, bgl, bwl, sg, sw)
+            cell, halo, n_loc, e_loc, sn, se, shard.local_graph, bgl, bwl, sg, sw)
         # local terms once per owner, replicated terms split evenly: the ranks' losses sum to the global loss
         loss = (on * r["nodes"][shard.owned_global]).sum() + (oe * r["edges"][shard.edge_global]).sum() \
             + ((osn * r["sn"]).sum() + (ose * r["se"]).sum()) / world
         loss.backward()
+        pgrads = ()
+        if real_cell:
+            # replicated parameters: every rank holds a partial gradient; one all_reduce sums them
+            partition.allreduce_gradients(cell.parameters())
+            pgrads = tuple(p.grad.clone() for _, p in sorted(cell.named_parameters()))
         q.put(_by_value((rank, shard.owned_global, shard.edge_global, on.detach(), oe.detach(), osn.detach(),
-                         ose.detach(), n_loc.grad.clone(), e_loc.grad.clone(), sn.grad.clone(), se.grad.clone())))
+                         ose.detach(), n_loc.grad.clone(), e_loc.grad.clone(), sn.grad.clone(), se.grad.clone())
+                        + pgrads))
     finally:
         dist.destroy_process_group()
 
 
-def test_partitioned_hierarchical_cell_matches_single_process():
+@pytest.mark.parametrize("real_cell", [False, True], ids=["oracle_cell", "real_cell_checkpointed"])
+def test_partitioned_hierarchical_cell_matches_single_process(real_cell):
+    """``real_cell``: the product HierarchicalGNNCell under its default reentrant checkpointing -- the
+    backward-time recompute of supernode_update must repeat the all_reduce of the node->supernode sums
+    (round-1 advisor finding: a hook removed after the forward call made the recompute skip it), and the
+    all-reduced weight gradients must equal the single-process ones."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_hworker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_hworker, args=(r, world, port, q, real_cell)) for r in range(world)]
     for p in procs:
         p.start()
     results = [_from_value(q.get(timeout=180)) for _ in range(world)]
@@ -249,11 +288,27 @@ def test_partitioned_hierarchical_cell_matches_single_process():
     ((on * r["nodes"]).sum() + (oe * r["edges"]).sum() + (osn * r["sn"]).sum() + (ose * r["se"]).sum()).backward()
     g_sn = torch.zeros_like(t["sn"])
     g_se = torch.zeros_like(t["se"])
-    for rank, owned, eglob, a, b, c, d, gn, ge, gsn, gse in results:
-        assert torch.allclose(a, on.detach()[owned], rtol=1e-5, atol=1e-6)
-        assert torch.allclose(b, oe.detach()[eglob], rtol=1e-5, atol=1e-6)
-        assert torch.allclose(c, osn.detach(), rtol=1e-5, atol=1e-6)      # replicated, identical everywhere
-        assert torch.allclose(d, ose.detach(), rtol=1e-5, atol=1e-6)
+    if real_cell:
+        from hierarchicalgnn_amd import HierarchicalGNNCell
+        ref_cell = HierarchicalGNNCell(HP)
+        ref_cell.load_state_dict(sd)
+        names = [n for n, _ in sorted(ref_cell.named_parameters())]
+        ref_params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        on2, oe2, osn2, ose2 = O.hgnn_cell(ref_params, "", HP, t["nodes"], t["edges"], t["sn"], t["se"],
+                                           graph, bg, bw, sg, sw)
+        ((on2 * r["nodes"]).sum() + (oe2 * r["edges"]).sum() + (osn2 * r["sn"]).sum()
+         + (ose2 * r["se"]).sum()).backward()
+        for res in results:
+            for nm, g in zip(names, res[11:]):
+                ref_g = ref_params[nm].grad
+                assert torch.allclose(g, ref_g, rtol=2e-4, atol=2e-5 * max(1.0, float(ref_g.abs().max()))), nm
+    # the real cell evaluates nn.Sequential modules, the oracle its own restatement: fp32 rounding differs
+    tol = dict(rtol=1e-4, atol=1e-5) if real_cell else dict(rtol=1e-5, atol=1e-6)
+    for rank, owned, eglob, a, b, c, d, gn, ge, gsn, gse, *_ in results:
+        assert torch.allclose(a, on.detach()[owned], **tol)
+        assert torch.allclose(b, oe.detach()[eglob], **tol)
+        assert torch.allclose(c, osn.detach(), **tol)      # replicated, identical everywhere
+        assert torch.allclose(d, ose.detach(), **tol)
         assert torch.allclose(gn, ref_in["nodes"].grad[owned], rtol=1e-4, atol=1e-5)
         assert torch.allclose(ge, ref_in["edges"].grad[eglob], rtol=1e-4, atol=1e-5)
         g_sn += gsn
