@@ -141,7 +141,10 @@ def get_plan(dst_index: torch.Tensor, dim_size: int, gather_index: Optional[torc
         _CACHE.move_to_end(key)
         _STATS["hits"] += 1
         return hit[0]
-    plan = GraphPlan(dst_index, dim_size, gather_index, n_src)
+    # cached objects outlive the call: build them as NORMAL tensors even under torch.inference_mode()
+    # (an inference tensor cached here could later not be saved for backward by a training-mode call)
+    with torch.inference_mode(False):
+        plan = GraphPlan(dst_index, dim_size, gather_index, n_src)
     # the strong references below pin the storages the key's data_ptr()s refer to
     _CACHE[key] = (plan, dst_index, gather_index)
     while len(_CACHE) > _CACHE_SIZE:
@@ -181,8 +184,9 @@ def get_index32(index: torch.Tensor, limit: int) -> torch.Tensor:
             return out
     lib = _lib.load()
     M = int(index.numel())
-    out = torch.empty(max(M, 1), dtype=torch.int32, device=index.device)
-    err = torch.zeros(1, dtype=torch.int32, device=index.device)
+    with torch.inference_mode(False):      # cached: must be a normal tensor (see get_plan)
+        out = torch.empty(max(M, 1), dtype=torch.int32, device=index.device)
+        err = torch.zeros(1, dtype=torch.int32, device=index.device)
     with torch.cuda.device(index.device):
         idx_c = index.contiguous()
         _lib.check(lib.hgnn_index_to_i32(_lib.ptr(idx_c), M, int(limit), _lib.ptr(out), _lib.ptr(err),
@@ -210,7 +214,8 @@ def memo(index: torch.Tensor, tag: str, make):
     if hit is not None:
         _MEMO.move_to_end(key)
         return hit[0]
-    out = make()
+    with torch.inference_mode(False):      # cached: normal tensors (see get_plan)
+        out = make()
     _MEMO[key] = (out, index)
     while len(_MEMO) > 4 * _CACHE_SIZE:
         _MEMO.popitem(last=False)

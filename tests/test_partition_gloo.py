@@ -383,3 +383,57 @@ def test_partitioned_ec_model_matches_single_process():
         seen[ids] += 1
         assert torch.allclose(scores, ref[ids], rtol=1e-5, atol=1e-6)
     assert int(seen.min()) == 1 and int(seen.max()) == 1          # every stored edge scored exactly once
+
+
+def _ec_train_worker(rank, world, port, q):
+    """one TRAINING step of the sharded EC-IN model: forward on my shard, my share of the loss, backward
+    through the halo / edge-pair exchanges, then ONE bucketed all_reduce of the replicated weights' gradients"""
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        x, ei, sd = _make_ec_problem()
+        sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        shard = partition.partition_event(x, ei, world, rank)
+        halo = partition.HaloExchange(shard, "cpu", mode="all_to_all")
+        pairs = partition.edge_pair_exchange(x, ei, world, rank, shard)
+        node_encode = lambda t: O.mlp_apply(sd, "ignn_block.node_encoder.", t, 3, "GELU", "GELU", True)
+        edge_encode = lambda xe, g: O.mlp_apply(sd, "ignn_block.edge_encoder.", torch.cat([xe[g[0]], xe[g[1]]], 1),
+                                                2, "GELU", "GELU", True)
+        head = lambda rows: O.mlp_apply(sd, "edge_classifier.", rows, 3, "GELU", None, True)
+        cells = [_OracleIGCell(sd, i) for i in range(EC_HP["n_interaction_graph_iters"])]
+        scores, ids = partition.distributed_ec_forward(node_encode, edge_encode, cells, head, shard, halo, pairs,
+                                                       x[shard.owned_global])
+        r = torch.randn(ei.shape[1], generator=torch.Generator().manual_seed(17))
+        (scores * r[ids]).sum().backward()          # each stored edge is scored on exactly one rank
+        names = sorted(sd)
+        partition.allreduce_gradients([sd[k] for k in names])
+        q.put(_by_value((rank,) + tuple(sd[k].grad for k in names)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partitioned_ec_training_step_weight_gradients():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ec_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [_from_value(q.get(timeout=180)) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, ei, sd = _make_ec_problem()
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    scores = O.ec_in_forward(sd, EC_HP, x, ei)
+    r = torch.randn(ei.shape[1], generator=torch.Generator().manual_seed(17))
+    (scores * r).sum().backward()
+    names = sorted(sd)
+    for res in results:
+        for k, g in zip(names, res[1:]):
+            ref = sd[k].grad
+            assert torch.allclose(g, ref, rtol=2e-4, atol=2e-5 * max(1.0, float(ref.abs().max()))), k
+    # both ranks hold the SAME summed gradient (what the optimiser step needs)
+    for a, b in zip(results[0][1:], results[1][1:]):
+        assert torch.equal(a, b)
