@@ -44,7 +44,9 @@ struct MlpArgs {
     int n_seg;
     int K1;       // columns stored in W[0] (multiple of 16)
     int K1_real;  // concatenated input width; < K1 only in small-K mode (K1_real <= 16, W[0] zero padded)
-    int out_real; // 1: the last layer is plain (no LayerNorm/act) with ONE real output (heads); else 0
+    int n_out_real;  // real output columns; < (tiles of the last layer)*16 only for PARTIAL kernels (heads with a
+                     // plain 1- or emb_dim-wide last layer, supernode encoder L-8): W/b/ln of the last layer are
+                     // zero padded to the tile width, statistics and stores use the real width
     const float* W[3];
     const float* b[3];
     const float* lnw[3];
@@ -70,11 +72,14 @@ __device__ __forceinline__ void stage_w(const float* __restrict__ W, int Kdim, i
 }
 
 // acc[T][r] (edge = lane&15, feature = 16T + 4*(lane>>4) + r): LayerNorm over features, then act
-template <int NT, int ACT, bool LN = true>
+// PARTIAL: only n_real < NT*16 features are real; the padded ones have zero weights and bias, so their
+// accumulators are exactly 0: they add nothing to the sum and mean^2 each to the squared deviations
+template <int NT, int ACT, bool LN = true, bool PARTIAL = false>
 __device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT], const float* __restrict__ lnw,
-                                              const float* __restrict__ lnb, int act, float eps, int g) {
+                                              const float* __restrict__ lnb, int act, float eps, int g,
+                                              int n_real = NT * 16) {
     if (!LN) return;  // plain last layer of a head: bias only
-    constexpr float inv_n = 1.0f / (float)(NT * 16);
+    const float inv_n = PARTIAL ? 1.0f / (float)n_real : 1.0f / (float)(NT * 16);
     float s = 0.f;
 #pragma unroll
     for (int T = 0; T < NT; ++T) s += (acc[T].x + acc[T].y) + (acc[T].z + acc[T].w);
@@ -89,6 +94,7 @@ __device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT], const float* __r
     }
     q += __shfl_xor(q, 16);
     q += __shfl_xor(q, 32);
+    if (PARTIAL) q -= (float)(NT * 16 - n_real) * mean * mean;
     const float rstd = 1.0f / sqrtf(q * inv_n + eps);
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
@@ -175,12 +181,29 @@ __device__ __forceinline__ void dense_from_regs(const f32x4 (&in)[NTI], f32x4 (&
     }
 }
 
-template <int NT>
+template <int NT, bool PARTIAL = false>
 __device__ __forceinline__ void store_out(const f32x4 (&acc)[NT], const MlpArgs& a, long long e, bool valid,
                                           int g) {
     if (!valid) return;
-    if (a.out_real == 1) {  // head: feature 0 of tile 0 (lanes g == 0, register x); the rest is padding
-        if (g == 0) a.out[e] = acc[0].x;
+    if constexpr (PARTIAL) {  // out[e][0 .. n_out_real): the columns past the real width are padding
+        const int nr = a.n_out_real;
+        float* op = a.out + (size_t)e * (size_t)nr;
+        if ((nr & 3) == 0) {
+#pragma unroll
+            for (int T = 0; T < NT; ++T) {
+                const int col = T * 16 + g * 4;
+                if (col < nr) *(f32x4*)(op + col) = acc[T];
+            }
+        } else {
+#pragma unroll
+            for (int T = 0; T < NT; ++T) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = T * 16 + g * 4 + r;
+                    if (col < nr) op[col] = acc[T][r];
+                }
+            }
+        }
         return;
     }
     constexpr int NOUT = NT * 16;
@@ -209,7 +232,9 @@ __device__ __forceinline__ void dump_pre(const f32x4 (&acc)[NT], float* base, lo
 // ACT_H / ACT_O: activation of the hidden layers / of the last layer (HGNN_ACT_*), or -1 = read
 // it from the descriptor per element (keeps rare combinations working without an instantiation)
 // PLAIN_LAST: the last layer has no LayerNorm / activation (classifier heads, width-1 output)
-template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, bool PLAIN_LAST = false, int NW = 4>
+// PARTIAL: the last layer's real width is a.n_out_real < its tile width (see MlpArgs)
+template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, bool PLAIN_LAST = false, int NW = 4,
+          bool PARTIAL = false>
 __global__ __launch_bounds__(NW * 64, MINW) void k_fused_mlp(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -331,10 +356,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_fused_mlp(const MlpArgs a) {
     __builtin_amdgcn_s_setprio(0);
     dump_pre<NT2>(acc2, a.save_pre[1], e, valid, g);
     if (!(a.ablate & 1))
-        layernorm_act<NT2, (NT3 == 0 ? ACT_O : ACT_H), !(PLAIN_LAST && NT3 == 0)>(acc2, a.lnw[1], a.lnb[1], a.act[1],
-                                                                                  a.eps, g);
+        layernorm_act<NT2, (NT3 == 0 ? ACT_O : ACT_H), !(PLAIN_LAST && NT3 == 0), (PARTIAL && NT3 == 0)>(
+            acc2, a.lnw[1], a.lnb[1], a.act[1], a.eps, g, NT3 == 0 ? a.n_out_real : NT2 * 16);
     if constexpr (NT3 == 0) {
-        store_out<NT2>(acc2, a, e, valid, g);
+        store_out<NT2, PARTIAL>(acc2, a, e, valid, g);
     } else {
         f32x4 acc3[NT3];
         init_bias<NT3>(acc3, a.b[2], g);
@@ -342,17 +367,19 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_fused_mlp(const MlpArgs a) {
         dense_from_regs<NT2, NT3, NW>(acc2, acc3, a.W[2], lds, wave, lane, a.ablate);
         __builtin_amdgcn_s_setprio(0);
         dump_pre<NT3>(acc3, a.save_pre[2], e, valid, g);
-        if (!(a.ablate & 1)) layernorm_act<NT3, ACT_O, !PLAIN_LAST>(acc3, a.lnw[2], a.lnb[2], a.act[2], a.eps, g);
-        store_out<NT3>(acc3, a, e, valid, g);
+        if (!(a.ablate & 1))
+            layernorm_act<NT3, ACT_O, !PLAIN_LAST, PARTIAL>(acc3, a.lnw[2], a.lnb[2], a.act[2], a.eps, g, a.n_out_real);
+        store_out<NT3, PARTIAL>(acc3, a, e, valid, g);
     }
 }
 
-template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, bool PLAIN_LAST = false, int NW = 4>
+template <int NT1, int NT2, int NT3, int MINW, int ACT_H, int ACT_O, bool PLAIN_LAST = false, int NW = 4,
+          bool PARTIAL = false>
 static int launch_mlp_act(const MlpArgs& a, hipStream_t s) {
     constexpr int maxnt = NT1 > NT2 ? (NT1 > NT3 ? NT1 : NT3) : (NT2 > NT3 ? NT2 : NT3);
     const size_t lds_bytes = (size_t)2 * maxnt * 256 * sizeof(float);
     const unsigned grid = (unsigned)ceil_div(a.M, NW * 16);
-    auto kern = k_fused_mlp<NT1, NT2, NT3, MINW, ACT_H, ACT_O, PLAIN_LAST, NW>;
+    auto kern = k_fused_mlp<NT1, NT2, NT3, MINW, ACT_H, ACT_O, PLAIN_LAST, NW, PARTIAL>;
     if (lds_bytes > 64 * 1024) {
         HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes));
@@ -360,6 +387,17 @@ static int launch_mlp_act(const MlpArgs& a, hipStream_t s) {
     kern<<<grid, NW * 64, lds_bytes, s>>>(a);
     HGNN_CHECK_HIP(hipGetLastError());
     return HGNN_OK;
+}
+
+// encoders whose output is narrower than their last tile row (supernode encoder: L - emb_dim,
+// BipartiteClassification/Models/HGNN_GMM.py:117): LayerNorm + activation over the real width
+template <int NT1, int NT2, int NT3, int MINW>
+static int launch_mlp_partial(const MlpArgs& a, hipStream_t s) {
+    const int n = NT3 == 0 ? 2 : 3;
+    bool gelu = true;
+    for (int l = 0; l < n; ++l) gelu = gelu && a.act[l] == HGNN_ACT_GELU;
+    if (gelu) return launch_mlp_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_GELU, false, 4, true>(a, s);
+    return launch_mlp_act<NT1, NT2, NT3, MINW, -1, -1, false, 4, true>(a, s);
 }
 
 template <int NT1, int NT2, int NT3, int MINW>
@@ -379,17 +417,24 @@ static int launch_mlp(const MlpArgs& a, hipStream_t s) {
     return launch_mlp_act<NT1, NT2, NT3, MINW, -1, -1>(a, s);
 }
 
-// classifier heads: K -> H -> H -> 1 (padded to 32 rows), LayerNorm + act on the two hidden layers only
+// heads: K -> H -> H -> w with a PLAIN last layer of w <= 32 real outputs (padded to 32 rows): the width-1
+// classifiers (IN.py:107-115, HGNN_GMM.py:313-321) and the emb_dim-wide embedding head (HGNN_GMM.py:74-82);
+// LayerNorm + act on the two hidden layers only
 template <int NTH, int MINW>
 static int launch_head(const MlpArgs& a, hipStream_t s) {
     if (a.act[0] == HGNN_ACT_GELU && a.act[1] == HGNN_ACT_GELU)
-        return launch_mlp_act<NTH, NTH, 2, MINW, HGNN_ACT_GELU, HGNN_ACT_NONE, true>(a, s);
+        return launch_mlp_act<NTH, NTH, 2, MINW, HGNN_ACT_GELU, HGNN_ACT_NONE, true, 4, true>(a, s);
     if (a.act[0] == HGNN_ACT_TANH && a.act[1] == HGNN_ACT_TANH)
-        return launch_mlp_act<NTH, NTH, 2, MINW, HGNN_ACT_TANH, HGNN_ACT_NONE, true>(a, s);
-    return launch_mlp_act<NTH, NTH, 2, MINW, -1, HGNN_ACT_NONE, true>(a, s);
+        return launch_mlp_act<NTH, NTH, 2, MINW, HGNN_ACT_TANH, HGNN_ACT_NONE, true, 4, true>(a, s);
+    return launch_mlp_act<NTH, NTH, 2, MINW, -1, HGNN_ACT_NONE, true, 4, true>(a, s);
 }
 
-static bool is_head(const hgnn_mlp_desc* d) { return d->width[d->n_layers] == 1; }
+// plain (no LayerNorm / activation) last layer of a 3-layer network = a head
+static bool is_head(const hgnn_mlp_desc* d) { return d->n_layers == 3 && d->ln_w[2] == nullptr; }
+// LayerNorm'ed last layer narrower than its zero-padded storage (supernode encoder)
+static bool is_partial(const hgnn_mlp_desc* d) {
+    return !is_head(d) && d->w_last_rows != 0 && d->w_last_rows != d->width[d->n_layers];
+}
 
 }  // namespace hgnn
 
@@ -421,15 +466,22 @@ extern "C" int hgnn_mlp_supported(const hgnn_mlp_desc* d) {
     const int o = d->width[n];
     if (n == 3 && d->width[2] != h) return 0;
     if (is_head(d)) {
-        // K -> H -> H -> 1: LayerNorm on the hidden layers only, plain last layer stored as 32 rows
-        if (n != 3 || d->w_last_rows != 32 || d->ln_w[2] != nullptr || d->act[2] != HGNN_ACT_NONE) return 0;
+        // K -> H -> H -> w (w <= 32): LayerNorm on the hidden layers only, plain last layer stored as 32 rows
+        if (o < 1 || o > 32 || d->w_last_rows != 32 || d->act[2] != HGNN_ACT_NONE) return 0;
         if (d->ln_w[0] == nullptr || d->ln_b[0] == nullptr || d->ln_w[1] == nullptr || d->ln_b[1] == nullptr) return 0;
         if (d->skip != nullptr) return 0;
         return (h == 64 || h == 128 || h == 256 || h == 512) ? 1 : 0;
     }
     for (int l = 0; l < n; ++l)
         if (d->ln_w[l] == nullptr || d->ln_b[l] == nullptr) return 0;
-    if (d->w_last_rows != 0 && d->w_last_rows != o) return 0;
+    if (is_partial(d)) {
+        // K -> 2P (-> 2P) -> o with o < P = w_last_rows real outputs, zero padded to P rows (W, b, ln_w, ln_b)
+        const int P = d->w_last_rows;
+        if (o < 4 || o >= P || (o & 3) != 0 || h != 2 * P || d->skip != nullptr) return 0;
+        for (int l = 0; l < n; ++l)
+            if (d->save_pre[l] != nullptr) return 0;
+        return (n == 3 && (P == 32 || P == 64 || P == 128 || P == 256)) ? 1 : 0;
+    }
     if (h != 2 * o) return 0;
     return (o == 32 || o == 64 || o == 128 || o == 256) ? 1 : 0;
 }
@@ -458,7 +510,7 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
     a.n_seg = d->n_seg;
     a.K1_real = d->width[0];
     a.K1 = d->w0_cols != 0 ? d->w0_cols : d->width[0];
-    a.out_real = is_head(d) ? 1 : 0;
+    a.n_out_real = d->width[d->n_layers];
     for (int l = 0; l < 3; ++l) {
         const bool on = l < d->n_layers;
         a.W[l] = on ? d->W[l] : nullptr;
@@ -479,7 +531,7 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
         HGNN_REQUIRE((uintptr_t)a.save_pre[l] % 16 == 0, "hgnn_mlp_forward_f32: save_pre[%d] must be 16-byte aligned", l);
     }
     HGNN_REQUIRE(!(is_head(d) && (d->save_pre[0] || d->save_pre[1] || d->save_pre[2])),
-                 "hgnn_mlp_forward_f32: save_pre is not available for width-1 heads");
+                 "hgnn_mlp_forward_f32: save_pre is not available for heads");
     a.eps = d->ln_eps;
     a.skip = d->skip;
     a.out = out;
@@ -498,6 +550,14 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
             case 128: return launch_head<8, 2>(a, stream);
             case 256: return launch_head<16, 2>(a, stream);
             case 512: return launch_head<32, 1>(a, stream);
+        }
+    }
+    if (is_partial(d)) {
+        switch (d->w_last_rows) {
+            case 32: return launch_mlp_partial<4, 4, 2, 2>(a, stream);
+            case 64: return launch_mlp_partial<8, 8, 4, 2>(a, stream);
+            case 128: return launch_mlp_partial<16, 16, 8, 2>(a, stream);
+            case 256: return launch_mlp_partial<32, 32, 16, 1>(a, stream);
         }
     }
     const int o = d->width[d->n_layers];

@@ -96,6 +96,13 @@ def _projected_segments(segments, M):
     return cand
 
 
+def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
+    """zero-pad the leading dimension to `rows` (padded parameters of a partial last layer)"""
+    out = torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    out[:t.shape[0]] = t
+    return out
+
+
 def _descriptor(net, segments, skip, dry=False):
     """(descriptor, keep-alive list, M, n_out) for hgnn_mlp_forward_f32, or None.  ``dry``: only decide
     supportability (no projection GEMMs are run; the descriptor must not be launched)."""
@@ -173,20 +180,29 @@ def _descriptor(net, segments, skip, dry=False):
             W = torch.nn.functional.pad(W.detach(), (0, 16 - K)).contiguous()
             keep.append(W)
             d.w0_cols = 16
+        lnw_t, lnb_t = (ln.weight, ln.bias) if ln is not None else (None, None)
+        o_l = int(lin.out_features)
         if l == n - 1 and ln is None:
-            if lin.out_features != 1:
+            if o_l > 32:
                 return None
-            # width-1 head: the plain last layer is stored zero-padded as 32 rows
-            Wp = torch.zeros((32, lin.in_features), dtype=torch.float32, device=W.device)
-            Wp[0] = W.detach()[0]
-            bp = torch.zeros(32, dtype=torch.float32, device=W.device)
-            bp[0] = b.detach()[0]
-            keep += [Wp, bp]
-            W, b = Wp, bp
+            # head (width-1 classifiers, emb_dim-wide embedding head): the plain last layer is stored
+            # zero-padded as 32 rows
+            W, b = _pad_rows(W.detach(), 32), _pad_rows(b.detach(), 32)
+            keep += [W, b]
             d.w_last_rows = 32
+        elif l == n - 1 and n == 3 and o_l not in (32, 64, 128, 256) and layers[0][0].out_features % 2 == 0:
+            # narrower than its tile row (supernode encoder, L - emb_dim outputs): Linear / LayerNorm
+            # parameters zero-padded to P = hidden / 2 rows; the kernel normalises over the real width
+            P = layers[0][0].out_features // 2
+            if not (P - 16 < o_l < P) or o_l % 4:
+                return None
+            W, b = _pad_rows(W.detach(), P), _pad_rows(b.detach(), P)
+            lnw_t, lnb_t = _pad_rows(ln.weight.detach(), P), _pad_rows(ln.bias.detach(), P)
+            keep += [W, b, lnw_t, lnb_t]
+            d.w_last_rows = P
         d.W[l], d.b[l] = W.data_ptr(), b.data_ptr()
         if ln is not None:
-            d.ln_w[l], d.ln_b[l] = ln.weight.data_ptr(), ln.bias.data_ptr()
+            d.ln_w[l], d.ln_b[l] = lnw_t.data_ptr(), lnb_t.data_ptr()
             if eps is None:
                 eps = ln.eps
             elif eps != ln.eps:

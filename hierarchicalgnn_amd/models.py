@@ -105,7 +105,8 @@ class InteractionGNNBlock(nn.Module):
             graph, order = graph_in, None
         emb = None
         if self.emb:
-            emb = nn.functional.normalize(self.output_layer(nodes.float()))
+            # HGNN_GMM.py:96-97: embedding head (plain emb_dim-wide last layer) on the fused kernel
+            emb = nn.functional.normalize(concat_mlp(self.output_layer, [(nodes.float(), None)]))
         return emb, nodes, edges, graph, order
 
     def forward(self, x, graph):

@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 12
+#define HGNN_ABI_VERSION 13
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -218,8 +218,12 @@ typedef struct hgnn_mlp_desc {
     int32_t w0_cols;             /* columns stored per row of W[0]: 0 = width[0]; must be 16 (zero
                                   * padded) in small-K mode, i.e. when width[0] <= 16 is not a
                                   * multiple of 16 (node / edge encoders, K = 3 / 6: IN.py:26-46)  */
-    int32_t w_last_rows;         /* rows stored in the last W / b: 0 = width[n]; must be 32 (zero
-                                  * padded) for a width-1 head (IN.py:107-115, HGNN_GMM.py:313-321) */
+    int32_t w_last_rows;         /* rows stored in the last W / b (and ln_w / ln_b): 0 = width[n].  Must be 32
+                                  * (zero padded) for a head = plain last layer of width[n] <= 32 real outputs
+                                  * (width-1 classifiers IN.py:107-115, HGNN_GMM.py:313-321; emb_dim-wide
+                                  * embedding head HGNN_GMM.py:74-82), and P = width[1] / 2 (zero padded) for a
+                                  * LayerNorm'ed last layer of P-16 < width[n] < P outputs (supernode encoder,
+                                  * L - emb_dim wide, HGNN_GMM.py:117): statistics and stores use width[n] */
     float* save_pre[3];          /* optional: [M, width[l+1]] buffers that receive layer l's output
                                   * BEFORE LayerNorm/activation (what a backward pass needs; hidden
                                   * activations are recomputed from it).  NULL = not saved.         */
@@ -240,9 +244,12 @@ typedef struct hgnn_mlp_desc {
  *   cell networks / encoders: widths K -> 2L (-> 2L) -> L, LayerNorm on every layer,
  *       L in {32, 64, 128, 256}; every segment a multiple of 16 floats wide, or K <= 16 in
  *       small-K mode (W[0] zero-padded to 16 columns, w0_cols = 16);
- *   heads: K -> H -> H -> 1, LayerNorm + activation on the two hidden layers, plain last layer
- *       (ln_w[2] = NULL, act[2] = NONE) stored zero-padded as 32 rows (w_last_rows = 32),
- *       H in {64, 128, 256, 512}, no skip; out is float[M]. */
+ *   heads: K -> H -> H -> w, 1 <= w <= 32, LayerNorm + activation on the two hidden layers, plain last
+ *       layer (ln_w[2] = NULL, act[2] = NONE) stored zero-padded as 32 rows (w_last_rows = 32),
+ *       H in {64, 128, 256, 512}, no skip; out is float[M, w];
+ *   narrow encoders: K -> 2P -> 2P -> o with P in {32, 64, 128, 256}, P-16 < o < P, o % 4 == 0, the last
+ *       layer's W / b / ln_w / ln_b zero padded to P rows (w_last_rows = P), no skip, no save_pre;
+ *       LayerNorm over the o real features; out is float[M, o]. */
 int hgnn_mlp_supported(const hgnn_mlp_desc* d);
 
 /* out[M, L] = MLP(cat_i seg_i[idx_i]) (+ skip).  No workspace; hidden activations stay in

@@ -68,8 +68,10 @@ def test_unsupported_shapes_fall_to_library_path():
         assert not fused.supported(odd, [(torch.randn(9, 24).cuda(), None)], None)
         noln = make_mlp(32, 64, 32, 2, layer_norm=False).cuda()
         assert not fused.supported(noln, [(torch.randn(9, 32).cuda(), None)], None)
-        sup = make_mlp(32, 64, 24, 3, layer_norm=True).cuda()         # supernode encoder: out = L - emb_dim
-        assert not fused.supported(sup, [(torch.randn(9, 32).cuda(), None)], None)
+        wide = make_mlp(32, 64, 40, 3, layer_norm=True).cuda()        # out > hidden / 2: no tile layout for it
+        assert not fused.supported(wide, [(torch.randn(9, 32).cuda(), None)], None)
+        odd_out = make_mlp(32, 64, 22, 3, layer_norm=True).cuda()     # out not a multiple of 4
+        assert not fused.supported(odd_out, [(torch.randn(9, 32).cuda(), None)], None)
 
 
 @pytest.mark.parametrize("latent", [32, 128])
@@ -305,3 +307,93 @@ def test_fused_paths_ignore_a_callers_autocast_region():
         res[ac] = [inf, out.detach(), table.grad, direct.grad] + [p.grad.clone() for p in net.parameters()]
     for a, b in zip(res[True], res[False]):
         assert a.dtype == torch.float32 and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("L,emb", [(32, 8), (64, 8), (128, 8), (256, 8), (256, 12), (64, 4)])
+def test_fused_supernode_encoder_partial_width(L, emb):
+    """supernode encoder L -> H -> H -> L - emb_dim (HGNN_GMM.py:117,:270): LayerNorm + GELU over an output
+    that is narrower than its last 16-feature tile row (248 at latent 256)"""
+    from hierarchicalgnn_amd import fused, make_mlp
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(L + emb)
+    M = 333
+    torch.manual_seed(L)
+    net = make_mlp(L, 2 * L, L - emb, 3, layer_norm=True, output_activation="GELU", hidden_activation="GELU")
+    for p in net.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.2 * torch.randn_like(p))
+    x = torch.randn(M, L, generator=g)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = O.mlp_apply(sd, "", x, 3, "GELU", "GELU", True)
+    net = net.cuda()
+    with torch.no_grad():
+        assert fused.supported(net, [(x.cuda(), None)], None)
+        n0 = fused.stats["fused_calls"]
+        out = fused.fused_concat_mlp(net, [(x.cuda(), None)], None)
+        assert fused.stats["fused_calls"] == n0 + 1
+    assert out.shape == (M, L - emb)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
+
+
+@pytest.mark.parametrize("L,emb,act", [(32, 8, "Tanh"), (128, 8, "Tanh"), (256, 8, "Tanh"), (256, 8, "GELU"), (64, 3, "Tanh"),
+                                       (128, 32, "GELU")])
+def test_fused_embedding_head(L, emb, act):
+    """embedding head L -> H -> H -> emb_dim with a plain last layer (HGNN_GMM.py:74-82, :96)"""
+    from hierarchicalgnn_amd import fused, make_mlp
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(L + emb)
+    M = 500
+    torch.manual_seed(L + 1)
+    net = make_mlp(L, 2 * L, emb, 3, layer_norm=True, output_activation=None, hidden_activation=act)
+    x = torch.randn(M, L, generator=g)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = O.mlp_apply(sd, "", x, 3, act, None, True)
+    net = net.cuda()
+    with torch.no_grad():
+        assert fused.supported(net, [(x.cuda(), None)], None)
+        out = fused.fused_concat_mlp(net, [(x.cuda(), None)], None)
+    assert out.shape == (M, emb)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
+
+
+def test_bc_forward_latent256_has_no_library_mlp():
+    """f2: every MLP of a BC-HGNN-GMM inference forward at the shipped config (latent 256) runs on the fused
+    kernel -- encoders (node, edge, supernode, superedge), 6 + 6 cells, embedding head, bipartite head; none
+    falls to the library path of mlp.concat_mlp"""
+    import json
+    import os
+    import conftest
+    from hierarchicalgnn_amd import fused, mlp, synth
+    from hierarchicalgnn_amd.models import BC_MessagePassing
+    with open(os.path.join(conftest.GOLDEN, "ref_configs.json")) as f:
+        raw = json.load(f)["BC-HGNN-GMM"]["raw"]
+    torch.manual_seed(0)
+    model = BC_MessagePassing(raw).cuda().eval()
+    x, ei = synth.trackml_event(3000, 18000, seed=5)
+    x, ei = x.cuda(), ei.cuda()
+    calls = {"n": 0}
+    real = mlp.concat_mlp
+
+    def counting(net, segments, skip=None, bf16_tail=False):
+        calls["n"] += 1
+        return real(net, segments, skip, bf16_tail)
+
+    import hierarchicalgnn_amd.gnn_utils as gu
+    import hierarchicalgnn_amd.models as mo
+    gu.concat_mlp = mo.concat_mlp = counting
+    try:
+        n0 = fused.stats["fused_calls"]
+        with torch.no_grad():
+            directed, emb, nodes, edges, _ = model.embed(x, ei)
+            bg, bw = synth.bipartite_assignment(3000, 40, 5, seed=2)
+            sg, sw = synth.super_graph(40, 10, seed=2)
+            means = torch.nn.functional.normalize(torch.randn(40, 8)).cuda()
+            n_out, sn_out, _, _ = model.hgnn_block(nodes, edges, directed, means, bg.cuda(), bw.cuda(), sg.cuda(),
+                                                    sw.cuda())
+            s = model.score(n_out, sn_out, bg.cuda())
+    finally:
+        gu.concat_mlp = mo.concat_mlp = real
+    assert bool(torch.isfinite(s).all())
+    expected = 2 + 2 * 6 + 1 + 2 + 4 * 6 + 1        # encoders, IGNN cells, emb head, super encoders, HGNN cells, head
+    assert calls["n"] == expected
+    assert fused.stats["fused_calls"] - n0 == expected
