@@ -19,7 +19,9 @@ from .ops import edge_dot, knn_radius
 
 
 def find_neighbors(embedding1, embedding2, r_max=1.0, k_max=10, return_dist2=False):
-    r = float(r_max.item()) if torch.is_tensor(r_max) else float(r_max)
+    # a tensor radius (the knn_radius buffer) is read by the kernel itself: no .item() host read
+    r = r_max if torch.is_tensor(r_max) and r_max.is_cuda else (float(r_max.item()) if torch.is_tensor(r_max)
+                                                                 else float(r_max))
     return knn_radius(embedding1, embedding2, k_max, r, return_dist2=return_dist2)
 
 
@@ -51,7 +53,7 @@ class DynamicGraphConstruction(nn.Module):
             else:
                 graph = torch.stack([ind[positive], idxs[positive]], dim=0)
             if self.training and graph.shape[1] > 0:
-                maximum_dist = d2[positive].max().sqrt()
+                maximum_dist = d2.max().clamp(min=0).sqrt()      # padding slots hold -1: max over the valid ones
                 self.knn_radius = 0.9 * self.knn_radius + 0.11 * maximum_dist
         return graph
 

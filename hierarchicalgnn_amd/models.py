@@ -178,22 +178,25 @@ class HierarchicalGNNBlock(nn.Module):
         self.hparams = hparams
         self._ckpt = bool(hparams.get("checkpointing", True))
 
-    def clustering(self, embeddings, graph):
+    def clustering(self, embeddings, graph, return_count=False):
         """HGNN_GMM.py:184-234 on the GPU (clustering.py): cluster id per hit, -1 = unclustered"""
         from .clustering import gmm_edge_clustering
-        return gmm_edge_clustering(embeddings, graph, self.score_cut, self.hparams, self.training)
+        return gmm_edge_clustering(embeddings, graph, self.score_cut, self.hparams, self.training,
+                                   return_count=return_count)
 
-    def hierarchy_from_clusters(self, embeddings, clusters):
+    def hierarchy_from_clusters(self, embeddings, clusters, n_clusters=None):
         """HGNN_GMM.py:251-260 given the cluster label of every hit (-1 = unclustered): centroids
         (scatter_mean, K8), L2-normalise, kNN super graph (symmetrised, sigmoid weights) and
-        bipartite graph (exp weights), both mean-normalised."""
+        bipartite graph (exp weights), both mean-normalised.  ``n_clusters`` (known from the clustering
+        step's single host read) avoids a second read of ``clusters.max()``."""
         from .ops import scatter_add
-        mask = clusters >= 0
-        n_clusters = int(clusters.max().item()) + 1
-        emb_c, lab_c = embeddings[mask], clusters[mask].contiguous()
-        sums = scatter_add(emb_c, lab_c, dim=0, dim_size=n_clusters)
-        counts = scatter_add(torch.ones(emb_c.shape[0], 1, device=emb_c.device), lab_c, dim=0,
-                             dim_size=n_clusters).clamp_(min=1)
+        if n_clusters is None:
+            n_clusters = int(clusters.max().item()) + 1
+        # unclustered hits (-1) are summed into a dummy row that is dropped: no data-dependent compaction
+        lab = torch.where(clusters >= 0, clusters, torch.full_like(clusters, n_clusters)).contiguous()
+        sums = scatter_add(embeddings, lab, dim=0, dim_size=n_clusters + 1, validate=False)[:n_clusters]
+        counts = scatter_add(torch.ones(embeddings.shape[0], 1, device=embeddings.device), lab, dim=0,
+                             dim_size=n_clusters + 1, validate=False)[:n_clusters].clamp_(min=1)
         means = nn.functional.normalize(sums / counts)
         super_graph, super_w = self.super_graph_construction(
             means, means, sym=True, norm=True, k=self.hparams["supergraph_sparsity"])
@@ -253,8 +256,8 @@ class BC_MessagePassing(nn.Module):
     def forward(self, x, graph):
         """HGNN_GMM.py:323-346: returns (bipartite_graph[2,B], bipartite_scores[B], embeddings[N,emb_dim])"""
         directed, emb, nodes, edges, _ = self.embed(x, graph)
-        clusters = self.hgnn_block.clustering(emb, directed)
-        means, bg, bw, sg, sw, _ = self.hgnn_block.hierarchy_from_clusters(emb, clusters)
+        clusters, n_clusters = self.hgnn_block.clustering(emb, directed, return_count=True)
+        means, bg, bw, sg, sw, _ = self.hgnn_block.hierarchy_from_clusters(emb, clusters, n_clusters)
         nodes, supernodes, _, _ = self.hgnn_block(nodes, edges, directed, means, bg, bw, sg, sw)
         return bg, self.score(nodes, supernodes, bg), emb
 

@@ -142,14 +142,16 @@ class _ScatterAdd(torch.autograd.Function):
 
 
 def scatter_add(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size: Optional[int] = None,
-                out=None, plan: Optional[GraphPlan] = None, weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out=None, plan: Optional[GraphPlan] = None, weight: Optional[torch.Tensor] = None,
+                validate: bool = True) -> torch.Tensor:
     """torch_scatter.scatter_add for the call shape the reference uses.
 
     src   Tensor[M, ...] float32; index LongTensor[M] (broadcast along features); dim must be 0.
     Returns a freshly allocated Tensor[dim_size, ...] with zero rows for absent
     destinations.  Differentiable w.r.t. ``src`` (and ``weight``).
     ``weight`` (Tensor[M] or [M,1]) is an extension: fused ``scatter_add(src*weight, ...)``
-    as at Modules/gnn_utils.py:143.
+    as at Modules/gnn_utils.py:143.  ``validate=False`` (an index this package produced itself, known to
+    be in range) skips the one host read a new plan makes to raise on out-of-range entries.
     """
     if dim != 0 and dim != -src.dim():
         raise RuntimeError("hierarchicalgnn_amd.scatter_add: only dim=0 is implemented (the reference's use)")
@@ -164,7 +166,7 @@ def scatter_add(src: torch.Tensor, index: torch.Tensor, dim: int = 0, dim_size: 
         dim_size = int(index.max().item()) + 1 if index.numel() else 0
     dim_size = int(dim_size)
     if plan is None:
-        plan = get_plan(index, dim_size)
+        plan = get_plan(index, dim_size, validate=validate)
     elif plan.M != index.numel() or plan.N != dim_size or plan.c.has_gather:
         raise RuntimeError("hierarchicalgnn_amd.scatter_add: plan does not match index/dim_size")
     trailing = tuple(src.shape[1:])
@@ -311,20 +313,34 @@ def edge_dot(A: torch.Tensor, ai: torch.Tensor, B: torch.Tensor, bi: torch.Tenso
     return _EdgeDot.apply(A, B, ai, bi)
 
 
-def knn_radius(query: torch.Tensor, points: torch.Tensor, k: int, radius: float, return_dist2: bool = False):
+def knn_radius(query: torch.Tensor, points: torch.Tensor, k: int, radius, return_dist2: bool = False):
     """<=k nearest `points` of every `query` row with squared distance < radius^2, ascending,
-    -1 padded: the idxs of frnn.frnn_grid_points (Modules/utils.py:232) for one batch."""
+    -1 padded: the idxs of frnn.frnn_grid_points (Modules/utils.py:232) for one batch.
+    ``radius``: a float, or a 1-element float32 device tensor (the module's ``knn_radius`` buffer) that the
+    kernel reads itself -- no host read of it."""
     _require_hip(query, "query")
     _require_hip(points, "points")
     if query.dim() != 2 or points.dim() != 2 or query.shape[1] != points.shape[1]:
         raise RuntimeError("knn_radius: query[N,D] and points[S,D] expected")
     q, p = query.detach().contiguous(), points.detach().contiguous()
     nq, D = int(q.shape[0]), int(q.shape[1])
+    r_dev, r_val = None, 0.0
+    if torch.is_tensor(radius):
+        if radius.numel() != 1 or radius.device != q.device:
+            raise RuntimeError("knn_radius: a tensor radius must have one element on the queries' device")
+        r_dev = radius.detach().reshape(1).float().contiguous()
+    else:
+        r_val = float(radius)
     idx = torch.empty((nq, int(k)), dtype=torch.int64, device=q.device)
     d2 = torch.empty((nq, int(k)), dtype=torch.float32, device=q.device) if return_dist2 else None
     lib = _lib.load()
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.hgnn_knn_workspace_bytes(nq, int(p.shape[0]), int(k), ctypes.byref(nbytes)),
+               "hgnn_knn_workspace_bytes")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=q.device) if nbytes.value else None
     with torch.cuda.device(q.device):
-        _lib.check(lib.hgnn_knn_radius_f32(_lib.ptr(q), nq, _lib.ptr(p), int(p.shape[0]), D, int(k),
-                                           ctypes.c_float(float(radius)), _lib.ptr(idx), _lib.ptr(d2),
-                                           _lib.current_stream(q.device)), "hgnn_knn_radius_f32")
+        _lib.check(lib.hgnn_knn_radius_ws_f32(_lib.ptr(q), nq, _lib.ptr(p), int(p.shape[0]), D, int(k),
+                                              ctypes.c_float(r_val), _lib.ptr(r_dev), _lib.ptr(idx), _lib.ptr(d2),
+                                              _lib.ptr(ws), nbytes.value, _lib.current_stream(q.device)),
+                   "hgnn_knn_radius_ws_f32")
     return (idx, d2) if return_dist2 else idx

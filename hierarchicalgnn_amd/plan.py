@@ -133,7 +133,7 @@ def _key(t: Optional[torch.Tensor]):
 
 
 def get_plan(dst_index: torch.Tensor, dim_size: int, gather_index: Optional[torch.Tensor] = None,
-             n_src: Optional[int] = None) -> GraphPlan:
+             n_src: Optional[int] = None, validate: bool = True) -> GraphPlan:
     """cached GraphPlan for (dst_index, dim_size[, gather_index, n_src])"""
     key = (_key(dst_index), int(dim_size), _key(gather_index), None if n_src is None else int(n_src))
     hit = _CACHE.get(key)
@@ -144,7 +144,7 @@ def get_plan(dst_index: torch.Tensor, dim_size: int, gather_index: Optional[torc
     # cached objects outlive the call: build them as NORMAL tensors even under torch.inference_mode()
     # (an inference tensor cached here could later not be saved for backward by a training-mode call)
     with torch.inference_mode(False):
-        plan = GraphPlan(dst_index, dim_size, gather_index, n_src)
+        plan = GraphPlan(dst_index, dim_size, gather_index, n_src, validate=validate)
     # the strong references below pin the storages the key's data_ptr()s refer to
     _CACHE[key] = (plan, dst_index, gather_index)
     while len(_CACHE) > _CACHE_SIZE:

@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 13
+#define HGNN_ABI_VERSION 14
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -184,6 +184,45 @@ int hgnn_index_to_i32(const int64_t* idx, int64_t M, int64_t limit, int32_t* out
  * DynamicGraphConstruction.forward (Modules/gnn_utils.py:194).  K in {1-6,8,10,12,16,20,32}. */
 int hgnn_knn_radius_f32(const float* query, int64_t nq, const float* points, int64_t np, int32_t D,
                         int32_t K, float radius, int64_t* idx_out, float* dist2_out, hgnn_stream_t stream);
+
+/* Same search with (i) the radius optionally read from DEVICE memory (`radius_dev` != NULL: the module's
+ * knn_radius buffer, Modules/gnn_utils.py:181,205 -- no host read of it) and (ii) a workspace that lets a
+ * search with few queries (the S x S super graph) split every query's candidates across workgroups and
+ * merge the per-slice lists afterwards (same result, ties included).  workspace may be NULL (no split). */
+int hgnn_knn_workspace_bytes(int64_t nq, int64_t np, int32_t K, size_t* bytes);
+int hgnn_knn_radius_ws_f32(const float* query, int64_t nq, const float* points, int64_t np, int32_t D,
+                           int32_t K, float radius, const float* radius_dev, int64_t* idx_out, float* dist2_out,
+                           void* workspace, size_t workspace_bytes, hgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * The hierarchy decision of HierarchicalGNNBlock.clustering
+ * (BipartiteClassification/Models/HGNN_GMM.py:162-234) without host round trips.
+ *
+ * hgnn_gmm2_fit_f32: 2-component 1-D Gaussian mixture of v[M] (the atanh edge likelihoods, :188-189), what
+ *   the reference gets from sklearn GaussianMixture(2).fit on the CPU (:192).  Deterministic 2-means start
+ *   from the data extremes, then at most max_iter EM passes with sklearn's stopping rule (change of the mean
+ *   log-likelihood < tol; reg_covar added to the variances) evaluated ON THE DEVICE: all passes are enqueued,
+ *   the ones after convergence return immediately.  state: double[HGNN_GMM_STATE] =
+ *   {w0, w1, mu0, mu1, var0, var1, previous lower bound, converged, EM passes run, min, max, c0, c1, cut,
+ *    last lower bound, -};  partials: double[HGNN_GMM_BLOCKS * 8] scratch;  ticket: one uint32 scratch.
+ * hgnn_gmm2_cut_f32: the cut x between the two means where sigmoid(r) P(left|x) = sigmoid(-r) P(right|x)
+ *   (:162-170, scipy fsolve in the reference; bisection here) -> state[13]; then, on the module's DEVICE
+ *   buffer score_cut[1] (:157): inf -> middle of the means (:196-197); in training mode, if the cut lies
+ *   between the means, score_cut = momentum * score_cut + (1 - momentum) * cut (:201-208).
+ * hgnn_cc_labels: weakly connected components over vertices 0..n-1 of the edges (src[e], dst[e]) whose
+ *   score[e] >= *cut (score == cut == NULL: all edges), :212-221 (cugraph in the reference).  labels[v] =
+ *   smallest vertex id of v's component (v itself if isolated); present[v] = 1 iff v is an endpoint of a
+ *   kept edge.  Lock-free union-find: one pass over the edges, one compression pass; no iteration to
+ *   convergence and therefore no host read.
+ * ------------------------------------------------------------------------ */
+#define HGNN_GMM_STATE 16
+#define HGNN_GMM_BLOCKS 1024
+int hgnn_gmm2_fit_f32(const float* v, int64_t M, int32_t max_iter, float tol, float reg_covar, double* state,
+                      double* partials, uint32_t* ticket, hgnn_stream_t stream);
+int hgnn_gmm2_cut_f32(double* state, float granularity, int32_t training, float momentum, float* score_cut,
+                      hgnn_stream_t stream);
+int hgnn_cc_labels(const int64_t* src, const int64_t* dst, int64_t M, int64_t n, const float* score,
+                   const float* cut, int32_t* labels, int32_t* present, hgnn_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused gather -> concat -> Linear -> LayerNorm -> act -> ... -> (+skip) MLP

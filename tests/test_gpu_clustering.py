@@ -107,3 +107,81 @@ def test_bc_model_forward_end_to_end_on_gpu():
     # the event is 70 disconnected chains: the hierarchy finds cluster-like groups, not one blob
     assert int(bg[1].max()) + 1 >= 10
     assert torch.allclose(emb.norm(dim=1), torch.ones_like(emb[:, 0]), atol=1e-5)
+
+
+def test_connected_components_long_chain_and_adversarial_labels():
+    """a single 200k-vertex path with randomly permuted vertex ids (the worst case of label propagation:
+    round-1's sweep loop stopped after 64 rounds) plus stars and isolated vertices: the union-find is exact"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components as cc
+    from hierarchicalgnn_amd.clustering import connected_components
+    g = torch.Generator().manual_seed(3)
+    n_chain, n = 200_000, 230_000
+    ids = torch.randperm(n_chain, generator=g)
+    src, dst = ids[:-1], ids[1:]
+    hub = torch.arange(n_chain, n_chain + 20_000)
+    star_src = hub
+    star_dst = (n_chain + (torch.arange(20_000) // 1000) * 1000)          # 20 stars of 1000
+    src = torch.cat([src, star_src])
+    dst = torch.cat([dst, star_dst])
+    perm = torch.randperm(src.numel(), generator=g)
+    src, dst = src[perm], dst[perm]
+    labels = connected_components(src.cuda(), dst.cuda(), n).cpu().numpy()
+    _, ref = cc(coo_matrix((np.ones(src.numel()), (src.numpy(), dst.numpy())), shape=(n, n)), directed=False)
+    assert _same_partition(labels, ref)
+    # the label of a component is its smallest vertex id; isolated vertices keep their own
+    assert labels[ids.numpy()].min() == labels[ids.numpy()].max() == 0
+    assert np.array_equal(labels[n_chain + 20_000:], np.arange(n_chain + 20_000, n))
+    again = connected_components(src.cuda(), dst.cuda(), n).cpu().numpy()
+    assert np.array_equal(labels, again)                                   # deterministic despite the races
+
+
+def test_device_cut_equals_the_host_root_solve_and_score_cut_bookkeeping():
+    from hierarchicalgnn_amd import _lib
+    from hierarchicalgnn_amd.clustering import gmm2_state, solve_cut
+    g = torch.Generator().manual_seed(4)
+    v = torch.cat([0.5 * torch.randn(50000, generator=g) - 1.0, 0.7 * torch.randn(30000, generator=g) + 2.0]).cuda()
+    st = gmm2_state(v)
+    host = st.cpu()
+    assert host[7] == 1.0 and 2 <= host[8] <= 100                          # converged on the device, in few passes
+    for r, training in ((0.0, 1), (5.0, 1), (5.0, 0)):
+        sc = torch.tensor([float("inf")], device="cuda")
+        _lib.check(_lib.load().hgnn_gmm2_cut_f32(_lib.ptr(st), r, training, 0.95, _lib.ptr(sc),
+                                                 _lib.current_stream(sc.device)))
+        cut_dev = float(st.cpu()[13])
+        cut_ref = solve_cut(st[0:2], st[2:4], st[4:6], r)
+        assert abs(cut_dev - cut_ref) < 1e-9
+        mid = 0.5 * float(host[2] + host[3])
+        expect = 0.95 * mid + 0.05 * cut_ref if training else mid          # inf -> middle, then the EMA
+        assert abs(float(sc) - expect) < 1e-5
+
+
+def test_clustering_makes_exactly_one_host_read():
+    """the whole decision (likelihoods, EM to convergence, cut, EMA, components, relabelling) under
+    torch.cuda.set_sync_debug_mode("error"): any implicit synchronisation raises; the single deliberate
+    read (the cluster count) is whitelisted and counted"""
+    from hierarchicalgnn_amd import clustering
+    from hierarchicalgnn_amd.clustering import GMMEdgeClustering
+    g = torch.Generator().manual_seed(5)
+    tracks, hits = 400, 9
+    centers = torch.nn.functional.normalize(torch.randn(tracks, 8, generator=g))
+    tid = torch.arange(tracks).repeat_interleave(hits)
+    n = tracks * hits
+    emb = torch.nn.functional.normalize(centers[tid] + 0.02 * torch.randn(n, 8, generator=g)).cuda()
+    i = torch.arange(n)
+    true_e = torch.stack([i[:-1], i[1:]])[:, tid[:-1] == tid[1:]]
+    fake_e = torch.stack([torch.randint(0, n, (2000,), generator=g), torch.randint(0, n, (2000,), generator=g)])
+    fake_e = fake_e[:, tid[fake_e[0]] != tid[fake_e[1]]]
+    graph = torch.cat([true_e, fake_e], 1)
+    graph = torch.cat([graph, graph.flip(0)], 1).cuda().contiguous()
+    m = GMMEdgeClustering(dict(min_cluster_size=3, cluster_granularity=0)).cuda().train()
+    m(emb, graph)                                                           # warm-up: code objects, index caches
+    torch.cuda.synchronize()
+    reads0 = clustering.stats["host_reads"]
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        clusters = m(emb, graph)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert clustering.stats["host_reads"] - reads0 == 1
+    assert _same_partition(clusters.cpu().numpy(), tid.numpy())

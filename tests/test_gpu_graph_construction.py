@@ -112,3 +112,27 @@ def test_knn_full_size_bipartite_properties():
     sel = torch.randint(0, 120_000, (200,), generator=g)
     idx_ref, d_ref = O.knn_radius(q[sel], p, 5, 0.8)
     assert rel_err(d2[sel].numpy(), d_ref.numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("nq,np_,K", [(10_000, 10_000, 10), (3000, 5000, 5), (700, 1300, 16), (100, 513, 3)])
+def test_knn_candidate_split_equals_the_single_pass(nq, np_, K):
+    """few queries (the S x S super graph): every query's candidates are searched by several workgroups and
+    the per-slice lists merged -- the result, ties and padding included, is the one-pass kernel's"""
+    import ctypes
+    from hierarchicalgnn_amd import _lib
+    from hierarchicalgnn_amd.ops import knn_radius
+    g = torch.Generator().manual_seed(nq + K)
+    pts = torch.nn.functional.normalize(torch.randn(np_, 8, generator=g))
+    pts[1::7] = pts[0::7][: pts[1::7].shape[0]]                  # exact duplicates: distance ties
+    q = pts[:nq].clone() if nq <= np_ else torch.nn.functional.normalize(torch.randn(nq, 8, generator=g))
+    q, pts = q.cuda(), pts.cuda()
+    r = torch.tensor([0.9], device="cuda")                       # radius read from device memory
+    idx, d2 = knn_radius(q, pts, K, r, return_dist2=True)
+    ref_idx = torch.empty_like(idx)
+    ref_d2 = torch.empty_like(d2)
+    _lib.check(_lib.load().hgnn_knn_radius_f32(_lib.ptr(q), nq, _lib.ptr(pts), np_, 8, K, ctypes.c_float(0.9),
+                                               _lib.ptr(ref_idx), _lib.ptr(ref_d2), _lib.current_stream(q.device)))
+    assert torch.equal(idx, ref_idx) and torch.equal(d2, ref_d2)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(_lib.load().hgnn_knn_workspace_bytes(nq, np_, K, ctypes.byref(nbytes)))
+    assert (nbytes.value > 0) == (np_ >= 512)                    # the split is actually exercised
