@@ -141,6 +141,76 @@ __global__ __launch_bounds__(WPB * 64) void k_seg_reduce(
     }
 }
 
+// Narrow rows (F <= 128 floats: RL <= 32 lanes cover a row, G = 64/RL >= 2 row slots per wave instruction).
+// With one wave per destination a wave moves only deg * F * 4 bytes (2 KB at F = 32, deg = 17) per chain of
+// dependent memory latencies (work-item triple -> row ids -> rows), and the chip runs out of waves before
+// it runs out of bandwidth (52-55 % of peak at F = 32 / 64).  Here every RL-lane GROUP of a wave owns its
+// own work item: G destinations per wave, each group walking its list U rows at a time.  Per wave
+// instruction the access pattern is the same (G whole rows), but a wave now carries G lists' worth of
+// bytes per latency chain, there are G times fewer waves to launch, and the cross-group shuffle reduction
+// disappears (a destination's rows are summed in list order by one lane group: still a fixed order).
+template <int RL, int U, bool HAS_W, bool HAS_RS, bool NT, int TAG, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_seg_reduce_grouped(
+    const float* __restrict__ src, int F, int nvec, const int32_t* __restrict__ src_row,
+    const int32_t* __restrict__ perm, const float* __restrict__ weight,
+    const float* __restrict__ row_scale, const int32_t* __restrict__ wi_begin,
+    const int32_t* __restrict__ wi_end, const int32_t* __restrict__ wi_target,
+    const int32_t* __restrict__ n_items_ptr, int64_t max_items, float* __restrict__ out,
+    float* __restrict__ partial) {
+    constexpr int G = 64 / RL;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / RL;
+    const int c = lane % RL;
+    const int64_t item = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * G + g;
+    const int n_items = *n_items_ptr;
+    const bool live = item < n_items && item < max_items;
+    int begin = 0, end = 0, target = 0;
+    if (live) {
+        begin = wi_begin[item];
+        end = wi_end[item];
+        target = wi_target[item];
+    }
+    const bool col_ok = c < nvec;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int base = begin; base < end; base += RL) {   // trip count differs between groups: lanes of a
+        const int n = (end - base) < RL ? (end - base) : RL;  // finished group simply idle (exec mask)
+        int my_row = 0;
+        float my_w = 1.f;
+        if (c < n) {
+            const int p = base + c;
+            my_row = src_row != nullptr ? src_row[p] : p;
+            if (HAS_W) my_w = weight[perm != nullptr ? perm[p] : p];
+            if (HAS_RS) my_w *= row_scale[my_row];
+        }
+        for (int j = 0; j < n; j += U) {
+            f32x4 val[U];
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = j + u;
+                const int from = g * RL + (e & (RL - 1));  // a lane of MY group: same loop iteration, active
+                const int r = __shfl(my_row, from);
+                w[u] = (HAS_W || HAS_RS) ? __shfl(my_w, from) : 1.f;
+                if (e < n && col_ok)
+                    val[u] = ld4(src + (size_t)r * (size_t)F + c * 4, NT);
+                else
+                    val[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (HAS_W || HAS_RS)
+                    acc += val[u] * w[u];
+                else
+                    acc += val[u];
+            }
+        }
+    }
+    if (live && col_ok) {
+        float* op = target >= 0 ? out + (size_t)target * (size_t)F : partial + (size_t)(~target) * (size_t)F;
+        *(f32x4*)(op + c * 4) = acc;
+    }
+}
+
 // any F (including F % 4 != 0): lanes stride over single floats, 64 columns per pass.
 template <bool HAS_W, bool HAS_RS>
 __global__ __launch_bounds__(256) void k_seg_reduce_scalar(
@@ -422,6 +492,26 @@ static void launch_seg3(const SegArgs& a, hipStream_t s) {
         a.wi_target, a.n_items, a.max_items, a.out, a.partial);
 }
 
+static int g_opt_seg_grouped = 0;  // narrow rows: 1 = one work item per RL-lane group; 0 (default) = one per wave.
+                                   // Measured A/B (profiles/r02_k1_widths.json): grouped is 2-5 % SLOWER at F = 32/64/128 --
+                                   // the narrow-row plateau (~50 % of peak at 128-B rows) is not a wave-count / latency limit
+
+template <int RL, int U, bool W, bool RS, int TAG>
+static void launch_seg_grouped(const SegArgs& a, hipStream_t s) {
+    constexpr int WPB = 4, G = 64 / RL;
+    const unsigned grid = (unsigned)ceil_div(a.max_items, WPB * G);
+    if (grid == 0) return;
+    const int nvec = a.F / 4;
+    if (g_opt_nt_loads)
+        k_seg_reduce_grouped<RL, U, W, RS, true, TAG, WPB><<<grid, WPB * 64, 0, s>>>(
+            a.src, a.F, nvec, a.src_row, a.perm, a.weight, a.row_scale, a.wi_begin, a.wi_end, a.wi_target,
+            a.n_items, a.max_items, a.out, a.partial);
+    else
+        k_seg_reduce_grouped<RL, U, W, RS, false, TAG, WPB><<<grid, WPB * 64, 0, s>>>(
+            a.src, a.F, nvec, a.src_row, a.perm, a.weight, a.row_scale, a.wi_begin, a.wi_end, a.wi_target,
+            a.n_items, a.max_items, a.out, a.partial);
+}
+
 template <int RL, int VPL, int U, bool W, bool RS, int TAG>
 static void launch_seg(const SegArgs& a, hipStream_t s) {
     if (g_opt_nt_loads)
@@ -465,6 +555,13 @@ static int dispatch_seg(const SegArgs& a, hipStream_t s) {
         return HGNN_OK;
     }
     const int nvec = F / 4;
+    if (g_opt_seg_grouped && nvec <= 32) {
+        if (nvec <= 4) launch_seg_grouped<4, 4, W, RS, TAG>(a, s);
+        else if (nvec <= 8) launch_seg_grouped<8, 8, W, RS, TAG>(a, s);
+        else if (nvec <= 16) launch_seg_grouped<16, 8, W, RS, TAG>(a, s);
+        else launch_seg_grouped<32, 8, W, RS, TAG>(a, s);
+        return HGNN_OK;
+    }
     if (nvec <= 4) launch_seg<4, 1, 4, W, RS, TAG>(a, s);
     else if (nvec <= 8) launch_seg<8, 1, 4, W, RS, TAG>(a, s);
     else if (nvec <= 16) launch_seg<16, 1, 4, W, RS, TAG>(a, s);
@@ -495,6 +592,7 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     else if (!strcmp(name, "seg_unroll")) g_opt_seg_unroll = value;
     else if (!strcmp(name, "seg_wpb")) g_opt_seg_wpb = value;
     else if (!strcmp(name, "seg_xcd")) g_opt_seg_xcd = value;
+    else if (!strcmp(name, "seg_grouped")) g_opt_seg_grouped = value;
     else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 31;
     else if (!strcmp(name, "mlp_split_variant")) g_opt_mlp_split_variant = value;
     else if (!strcmp(name, "mlp_f32_waves")) g_opt_mlp_f32_waves = value;

@@ -103,6 +103,8 @@ int hgnn_sizeof_mlp_desc(void);
 
 /* Process-wide switches for A/B measurements:
  *   "nt_loads", "nt_stores", "seg_unroll", "seg_wpb", "seg_xcd"   K1..K6 launch shape / cache policy
+ *   "seg_grouped"  rows of <= 128 floats: 0 (default) one work item per wave with a cross-group reduction,
+ *                  1 one work item per row-covering lane group (64/RL destinations per wave; A/B: 2-5 % slower)
  *   "mlp_bf16_shape" bf16 MLP launch shape: 0 = 16 edges/wave, 2-deep weight ring; 1 (default) = 32
  *                  edges/wave, 3-deep ring for wide layers
  *   "mlp_f32_waves" fp32 fused MLP, L=256 two-layer kernel: 4 (default) or 8 waves per workgroup (A/B:
