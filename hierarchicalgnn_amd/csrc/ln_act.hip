@@ -37,11 +37,34 @@ __device__ __forceinline__ float act_grad(float y, float a, int act) {
     }
 }
 
-template <int NV, bool BACKWARD>
-__global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ z, const float* __restrict__ da,
+// rows in fp32 (T = float) or bf16 (T = unsigned short: the training path of BASELINE config 4; statistics and
+// all arithmetic stay fp32, one rounding per stored element)
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld_row4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 ld_row4(const unsigned short* p) {
+    const u16x4 v = *(const u16x4*)p;
+    f32x4 o;
+    o.x = __builtin_bit_cast(float, (unsigned)v[0] << 16);
+    o.y = __builtin_bit_cast(float, (unsigned)v[1] << 16);
+    o.z = __builtin_bit_cast(float, (unsigned)v[2] << 16);
+    o.w = __builtin_bit_cast(float, (unsigned)v[3] << 16);
+    return o;
+}
+__device__ __forceinline__ void st_row4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void st_row4(unsigned short* p, f32x4 v) {
+    u16x4 o;
+    o[0] = __builtin_bit_cast(unsigned short, (__bf16)v.x);
+    o[1] = __builtin_bit_cast(unsigned short, (__bf16)v.y);
+    o[2] = __builtin_bit_cast(unsigned short, (__bf16)v.z);
+    o[3] = __builtin_bit_cast(unsigned short, (__bf16)v.w);
+    *(u16x4*)p = o;
+}
+
+template <int NV, bool BACKWARD, typename T>
+__global__ __launch_bounds__(256) void k_ln_act(const T* __restrict__ z, const T* __restrict__ da,
                                                 long long M, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, int act, float eps,
-                                                float* __restrict__ out, float* __restrict__ partials) {
+                                                T* __restrict__ out, float* __restrict__ partials) {
     constexpr int W = NV * 64;
     constexpr float inv_w = 1.0f / (float)W;
     __shared__ float red[BACKWARD ? 4 * 3 * W : 1];
@@ -69,13 +92,13 @@ __global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ z, con
         float s = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            x[v] = *(const f32x4*)(z + off + v * 64);
+            x[v] = ld_row4(z + off + v * 64);
             s += (x[v].x + x[v].y) + (x[v].z + x[v].w);
         }
         f32x4 g[BACKWARD ? NV : 1];
         if constexpr (BACKWARD) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) g[v] = *(const f32x4*)(da + off + v * 64);
+            for (int v = 0; v < NV; ++v) g[v] = ld_row4(da + off + v * 64);
         }
         const float mean = row16_sum(s) * inv_w;
         float q = 0.f;
@@ -96,7 +119,7 @@ __global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ z, con
                 o.y = act_apply(fmaf(x[v].y * rstd, gm[v].y, bt[v].y), act);
                 o.z = act_apply(fmaf(x[v].z * rstd, gm[v].z, bt[v].z), act);
                 o.w = act_apply(fmaf(x[v].w * rstd, gm[v].w, bt[v].w), act);
-                if (valid) *(f32x4*)(out + off + v * 64) = o;
+                if (valid) st_row4(out + off + v * 64, o);
             }
         } else {
             // x <- xhat, g <- dy * gamma;  column sums of dy*xhat and dy;  row sums of g and g*xhat
@@ -134,7 +157,7 @@ __global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ z, con
                 o.z = rstd * (g[v].z - mg - x[v].z * mgx);
                 o.w = rstd * (g[v].w - mg - x[v].w * mgx);
                 if (valid) {
-                    *(f32x4*)(out + off + v * 64) = o;
+                    st_row4(out + off + v * 64, o);
                     s_dz[v].x += o.x; s_dz[v].y += o.y; s_dz[v].z += o.z; s_dz[v].w += o.w;
                 }
             }
@@ -161,16 +184,16 @@ __global__ __launch_bounds__(256) void k_ln_act(const float* __restrict__ z, con
     }
 }
 
-template <bool BACKWARD>
-static int launch_ln_act(const float* z, const float* da, int64_t M, int W, const float* gamma, const float* beta,
-                         int act, float eps, float* out, float* partials, hipStream_t s) {
+template <bool BACKWARD, typename T>
+static int launch_ln_act(const T* z, const T* da, int64_t M, int W, const float* gamma, const float* beta,
+                         int act, float eps, T* out, float* partials, hipStream_t s) {
     const unsigned grid = BACKWARD ? (unsigned)kLnActBlocks
                                    : (unsigned)(ceil_div(M, 16) < 4096 ? ceil_div(M, 16) : 4096);
     switch (W / 64) {
-        case 1: k_ln_act<1, BACKWARD><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
-        case 2: k_ln_act<2, BACKWARD><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
-        case 4: k_ln_act<4, BACKWARD><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
-        case 8: k_ln_act<8, BACKWARD><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
+        case 1: k_ln_act<1, BACKWARD, T><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
+        case 2: k_ln_act<2, BACKWARD, T><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
+        case 4: k_ln_act<4, BACKWARD, T><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
+        case 8: k_ln_act<8, BACKWARD, T><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
         default:
             set_error("hgnn_ln_act: width %d has no instantiation (64, 128, 256, 512)", W);
             return HGNN_ERR_UNSUPPORTED;
@@ -199,7 +222,7 @@ extern "C" int hgnn_ln_act_forward_f32(const float* z, int64_t M, int32_t W, con
                                        int32_t act, float eps, float* out, hgnn_stream_t stream) {
     const int rc = check_ln_act(z, M, W, gamma, beta, act, out, "hgnn_ln_act_forward_f32");
     if (rc != HGNN_OK || M == 0) return rc;
-    return launch_ln_act<false>(z, nullptr, M, W, gamma, beta, act, eps, out, nullptr, (hipStream_t)stream);
+    return launch_ln_act<false, float>(z, nullptr, M, W, gamma, beta, act, eps, out, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int hgnn_ln_act_backward_f32(const float* z, const float* grad_out, int64_t M, int32_t W,
@@ -212,5 +235,26 @@ extern "C" int hgnn_ln_act_backward_f32(const float* z, const float* grad_out, i
     HGNN_REQUIRE(M == 0 || (grad_out != nullptr && (uintptr_t)grad_out % 16 == 0),
                  "hgnn_ln_act_backward_f32: grad_out is NULL or not 16-byte aligned");
     // M == 0 still runs: every workgroup writes its (zero) partials
-    return launch_ln_act<true>(z, grad_out, M, W, gamma, beta, act, eps, grad_z, partials, (hipStream_t)stream);
+    return launch_ln_act<true, float>(z, grad_out, M, W, gamma, beta, act, eps, grad_z, partials, (hipStream_t)stream);
+}
+
+extern "C" int hgnn_ln_act_forward_bf16(const void* z, int64_t M, int32_t W, const float* gamma, const float* beta,
+                                        int32_t act, float eps, void* out, hgnn_stream_t stream) {
+    const int rc = check_ln_act(z, M, W, gamma, beta, act, out, "hgnn_ln_act_forward_bf16");
+    if (rc != HGNN_OK || M == 0) return rc;
+    return launch_ln_act<false, unsigned short>((const unsigned short*)z, nullptr, M, W, gamma, beta, act, eps,
+                                                (unsigned short*)out, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int hgnn_ln_act_backward_bf16(const void* z, const void* grad_out, int64_t M, int32_t W,
+                                         const float* gamma, const float* beta, int32_t act, float eps,
+                                         void* grad_z, float* partials, hgnn_stream_t stream) {
+    const int rc = check_ln_act(z, M, W, gamma, beta, act, grad_z, "hgnn_ln_act_backward_bf16");
+    if (rc != HGNN_OK) return rc;
+    HGNN_REQUIRE(partials != nullptr && (uintptr_t)partials % 16 == 0,
+                 "hgnn_ln_act_backward_bf16: partials must be a 16-byte aligned [HGNN_LN_ACT_BLOCKS][3][W] buffer");
+    HGNN_REQUIRE(M == 0 || (grad_out != nullptr && (uintptr_t)grad_out % 16 == 0),
+                 "hgnn_ln_act_backward_bf16: grad_out is NULL or not 16-byte aligned");
+    return launch_ln_act<true, unsigned short>((const unsigned short*)z, (const unsigned short*)grad_out, M, W, gamma,
+                                               beta, act, eps, (unsigned short*)grad_z, partials, (hipStream_t)stream);
 }

@@ -50,6 +50,8 @@ struct Args {
     const unsigned short* pre_table[2];  // pre-projected gathered segments, bf16 [rows, width1] (hgnn_mlp_desc.n_pre)
     const int32_t* pre_index[2];
     int n_pre;
+    unsigned short* save_pre[3];  // optional bf16 [M, width_l] dumps of each layer's pre-LayerNorm output: what the
+                                  // bf16 training path's backward needs (hgnn_ln_act_backward_bf16, hgnn_wgrad_bf16)
     int ablate;  // DIAGNOSTIC (hgnn_set_option "mlp_ablate", wrong results): 1 = weights from chunk 0 only
                  // (L1-resident), 2 = no LayerNorm / activation, 4 = only the first input panel is loaded,
                  // 8 = no per-panel barriers, 16 = B reads from chunk 0 only
@@ -279,6 +281,29 @@ __device__ __forceinline__ void store_out(const f32x4 (&acc)[NT][NJ], const Args
     }
 }
 
+// training: this wave's slice of the layer's pre-LayerNorm rows z[e][f] -> bf16 [M, NW*NT*16] (wave-uniform base)
+template <int NT, int NW, int NJ>
+__device__ __forceinline__ void dump_pre(const f32x4 (&acc)[NT][NJ], unsigned short* base, long long M, long long e0,
+                                         int wave, int ei, int g) {
+    if (base == nullptr) return;
+    constexpr int NOUT = NW * NT * 16;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long e = e0 + j * 16 + ei;
+        if (e >= M) continue;
+        const size_t off = (size_t)e * NOUT + (size_t)(wave * NT * 16 + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            u16x4 o;
+            o[0] = bf16_bits(acc[t][j].x);
+            o[1] = bf16_bits(acc[t][j].y);
+            o[2] = bf16_bits(acc[t][j].z);
+            o[3] = bf16_bits(acc[t][j].w);
+            *(u16x4*)(base + off + t * 16) = o;
+        }
+    }
+}
+
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // NW waves x NJ 16-row tiles per workgroup; NTl: 16-feature tiles PER WAVE of layer l (= width_l / (16 NW));
@@ -390,6 +415,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
             if (!(a.ablate & 8)) __syncthreads();
         }
     }
+    dump_pre<NT1, NW, NJ>(acc1, a.save_pre[0], a.M, e0, wave, ei, g);
     layernorm_act<NT1, ACT_H, NW, NJ>(acc1, a.lnw[0] + wave * NT1 * 16 + 4 * g, a.lnb[0] + wave * NT1 * 16 + 4 * g, a.act[0],
                               a.eps, red, wave, ei, g, a.ablate);
     // (the barrier inside layernorm_act also means: every wave is done reading the panels)
@@ -405,6 +431,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
         ring_fill<NT2, NW>(w, wp, NC2);
         gemm_lds<NT2, HRS, VAR, NW, NJ>(acc2, w, wp, 0, NC2, smem + ei * HRS + g * 16, NC2, a.ablate);
     }
+    dump_pre<NT2, NW, NJ>(acc2, a.save_pre[1], a.M, e0, wave, ei, g);
     if constexpr (NT3 == 0) {
         layernorm_act<NT2, ACT_O, NW, NJ>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
                                   a.act[1], a.eps, red, wave, ei, g, a.ablate);
@@ -423,6 +450,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
             ring_fill<NT3, NW>(w, wp, NC2);
             gemm_lds<NT3, HRS, VAR, NW, NJ>(acc3, w, wp, 0, NC2, smem + ei * HRS + g * 16, NC2, a.ablate);
         }
+        dump_pre<NT3, NW, NJ>(acc3, a.save_pre[2], a.M, e0, wave, ei, g);
         layernorm_act<NT3, ACT_O, NW, NJ>(acc3, a.lnw[2] + wave * NT3 * 16 + 4 * g, a.lnb[2] + wave * NT3 * 16 + 4 * g,
                                   a.act[2], a.eps, red, wave, ei, g, a.ablate);
         store_out<NT3, NW, NJ>(acc3, a, e0, wave, ei, g);
@@ -483,7 +511,6 @@ extern "C" int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d) {
     const int n = d->n_layers;
     for (int l = 0; l < n; ++l)
         if (d->W[l] == nullptr || d->b[l] == nullptr || d->ln_w[l] == nullptr || d->ln_b[l] == nullptr) return 0;
-    if (d->save_pre[0] || d->save_pre[1] || d->save_pre[2]) return 0;
     if (d->n_pre < 0 || d->n_pre > 2) return 0;
     for (int s = 0; s < d->n_pre; ++s)
         if (d->pre_table[s] == nullptr || d->pre_index[s] == nullptr) return 0;
@@ -540,6 +567,10 @@ extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hg
         HGNN_REQUIRE((uintptr_t)a.pre_table[s] % 8 == 0, "hgnn_mlp_forward_bf16_split: pre_table[%d] must be 8-byte aligned", s);
     }
     a.ablate = g_opt_mlp_ablate;
+    for (int l = 0; l < 3; ++l) {
+        a.save_pre[l] = l < d->n_layers ? (unsigned short*)d->save_pre[l] : nullptr;   // bf16 rows here
+        HGNN_REQUIRE((uintptr_t)a.save_pre[l] % 8 == 0, "hgnn_mlp_forward_bf16_split: save_pre[%d] must be 8-byte aligned", l);
+    }
     HGNN_REQUIRE((uintptr_t)out % 8 == 0 && (uintptr_t)a.skip % 8 == 0,
                  "hgnn_mlp_forward_bf16_split: out/skip must be 8-byte aligned");
     const int o = d->width[d->n_layers];

@@ -425,10 +425,13 @@ def _ln_act_forward(z, gamma, beta, act, eps):
     out = torch.empty_like(z)
     M, W = int(z.shape[0]), int(z.shape[1])
     if M:
+        lib = _lib.load()
+        fn = lib.hgnn_ln_act_forward_bf16 if z.dtype == torch.bfloat16 else lib.hgnn_ln_act_forward_f32
         with torch.cuda.device(z.device):
-            _lib.check(_lib.load().hgnn_ln_act_forward_f32(
-                _lib.ptr(z), M, W, _lib.ptr(gamma.detach().contiguous()), _lib.ptr(beta.detach().contiguous()),
-                int(act), float(eps), _lib.ptr(out), _lib.current_stream(z.device)), "hgnn_ln_act_forward_f32")
+            _lib.check(fn(
+                _lib.ptr(z), M, W, _lib.ptr(gamma.detach().float().contiguous()),
+                _lib.ptr(beta.detach().float().contiguous()),
+                int(act), float(eps), _lib.ptr(out), _lib.current_stream(z.device)), "hgnn_ln_act_forward")
     return out
 
 
@@ -437,12 +440,14 @@ def _ln_act_backward(z, grad_out, gamma, beta, act, eps):
     M, W = int(z.shape[0]), int(z.shape[1])
     dz = torch.empty_like(z)
     partials = torch.empty((_lib.LN_ACT_BLOCKS, 3, W), dtype=torch.float32, device=z.device)
-    go = grad_out.contiguous()
+    go = grad_out.contiguous().to(z.dtype)
+    lib = _lib.load()
+    fn = lib.hgnn_ln_act_backward_bf16 if z.dtype == torch.bfloat16 else lib.hgnn_ln_act_backward_f32
     with torch.cuda.device(z.device):
-        _lib.check(_lib.load().hgnn_ln_act_backward_f32(
-            _lib.ptr(z), _lib.ptr(go), M, W, _lib.ptr(gamma.detach().contiguous()),
-            _lib.ptr(beta.detach().contiguous()), int(act), float(eps), _lib.ptr(dz), _lib.ptr(partials),
-            _lib.current_stream(z.device)), "hgnn_ln_act_backward_f32")
+        _lib.check(fn(
+            _lib.ptr(z), _lib.ptr(go), M, W, _lib.ptr(gamma.detach().float().contiguous()),
+            _lib.ptr(beta.detach().float().contiguous()), int(act), float(eps), _lib.ptr(dz), _lib.ptr(partials),
+            _lib.current_stream(z.device)), "hgnn_ln_act_backward")
     sums = partials.sum(dim=0)
     return dz, sums[0], sums[1], sums[2]
 
@@ -602,9 +607,21 @@ class _FusedMLPTrain(torch.autograd.Function):
 
 
 def supported_train(net, segments, skip) -> bool:
-    """differentiable fused path: cell networks (LayerNorm on every layer, 16-aligned segments)"""
+    """differentiable fused path: cell networks (LayerNorm on every layer, 16-aligned segments); bf16 rows:
+    the feature-split kernel's shapes at latent 128 / 256 (``_FusedMLPTrainBf16``)"""
     if not _train_enabled or not torch.is_grad_enabled():
         return False
+    if _is_bf16(segments):
+        if not _train_bf16_enabled or not _wants_split(net, segments):
+            return False
+        layers = _parse(net)
+        if any(lin.out_features not in (64, 128, 256, 512) for lin, _, _ in layers):
+            return False                              # widths of the bf16 LayerNorm / activation row kernels
+        try:
+            desc = _descriptor_bf16(net, segments, skip, split=True, dry=True)
+        except RuntimeError:
+            return False
+        return desc is not None and bool(_lib.load().hgnn_mlp_supported_bf16_split(ctypes.byref(desc[0])))
     try:
         desc = _descriptor(net, segments, skip, dry=True)
     except RuntimeError:
@@ -625,4 +642,134 @@ def fused_concat_mlp_train(net, segments, skip: Optional[torch.Tensor]):
     tables = [t for t, _ in segments]
     indices = tuple(i for _, i in segments)
     extra = [skip] if skip is not None else []
-    return _FusedMLPTrain.apply(net, indices, skip is not None, *tables, *extra, *params)
+    fn = _FusedMLPTrainBf16 if _is_bf16(segments) else _FusedMLPTrain
+    return fn.apply(net, indices, skip is not None, *tables, *extra, *params)
+
+
+# --------------------------------------------------------------------------- bf16 training variant
+_train_bf16_enabled = True
+_wgrad_hip = True          # A/B: hand-written split-K bf16-MFMA weight gradient vs the library's TN GEMM
+
+
+def set_train_bf16(flag: bool, wgrad_hip: bool = True) -> None:
+    global _train_bf16_enabled, _wgrad_hip
+    _train_bf16_enabled, _wgrad_hip = bool(flag), bool(wgrad_hip)
+
+
+def _wgrad(dz: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+    """fp32 dz^T rows of bf16 operands"""
+    if _wgrad_hip:
+        from .ops import wgrad_bf16
+        return wgrad_bf16(dz, rows)
+    return (dz.t() @ rows).float()
+
+
+def _seg_reduce_wide(plan, dz):
+    """segmented reduce of bf16 rows wider than the bf16 row kernel's 512 columns: column blocks"""
+    from .ops import _seg_reduce
+    F = int(dz.shape[1])
+    if F <= 512:
+        return _seg_reduce(plan, dz, None, None)
+    return torch.cat([_seg_reduce(plan, dz[:, c:c + 512].contiguous(), None, None) for c in range(0, F, 512)], dim=1)
+
+
+class _FusedMLPTrainBf16(torch.autograd.Function):
+    """Differentiable fused MLP on bf16 rows (BASELINE config 4 dtype; fp32 master weights).
+
+    forward : the feature-split bf16-MFMA kernel, additionally dumping every layer's pre-LayerNorm rows
+              z_l in bf16 (``hgnn_mlp_desc.save_pre``);
+    backward: per layer ONE HIP row pass for activation' -> LayerNorm backward -> dgamma / dbeta / dbias
+              (``hgnn_ln_act_backward_bf16``), the hidden activations recomputed from z_l in one more
+              (``hgnn_ln_act_forward_bf16``), the WEIGHT gradients by the hand-written split-K bf16-MFMA
+              kernel ``hgnn_wgrad_bf16`` (fp32 accumulation, deterministic: the library's TN GEMM reaches
+              140-370 TFLOP/s on this tall reduction, 3.3-4.3x slower), the data gradients by bf16
+              library GEMMs; gathered segments factor through the atomics-free segmented reduce exactly
+              as in the fp32 variant (N-row products instead of M-row ones)."""
+
+    @staticmethod
+    def forward(ctx, net, indices, has_skip, *tensors):
+        n_seg = len(indices)
+        tables = list(tensors[:n_seg])
+        skip = tensors[n_seg] if has_skip else None
+        params = tensors[n_seg + (1 if has_skip else 0):]
+        segments = [(t, i) for t, i in zip(tables, indices)]
+        desc = _descriptor_bf16(net, segments, skip, split=True)
+        if desc is None:
+            raise RuntimeError("fused_concat_mlp_train (bf16): unsupported arguments (call supported_train() first)")
+        d, keep, M, n_out = desc
+        n = int(d.n_layers)
+        dev = tables[0].device
+        zs = [torch.empty((M, int(d.width[l + 1])), dtype=torch.bfloat16, device=dev) for l in range(n)]
+        for l in range(n):
+            d.save_pre[l] = zs[l].data_ptr() if M else None
+        out = torch.empty((M, n_out), dtype=torch.bfloat16, device=dev)
+        if M:
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().hgnn_mlp_forward_bf16_split(ctypes.byref(d), _lib.ptr(out),
+                                                                   _lib.current_stream(dev)),
+                           "hgnn_mlp_forward_bf16_split")
+        del keep
+        stats["fused_train_calls"] += 1
+        ctx.indices, ctx.has_skip, ctx.n = indices, has_skip, n
+        ctx.acts = [int(d.act[l]) for l in range(n)]
+        ctx.eps = float(d.ln_eps)
+        ctx.save_for_backward(*tables, *params, *zs)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        with torch.autocast("cuda", enabled=False):
+            return _FusedMLPTrainBf16._backward(ctx, grad_out)
+
+    @staticmethod
+    def _backward(ctx, grad_out):
+        from .plan import get_plan
+        n, indices = ctx.n, ctx.indices
+        n_seg = len(indices)
+        saved = ctx.saved_tensors
+        tables = saved[:n_seg]
+        params = saved[n_seg:n_seg + 4 * n]
+        zs = saved[n_seg + 4 * n:]
+        W = [params[4 * l] for l in range(n)]
+        lnw = [params[4 * l + 2] for l in range(n)]
+        lnb = [params[4 * l + 3] for l in range(n)]
+        bf = torch.bfloat16
+        g = grad_out.contiguous().to(bf)
+        grads_params = [None] * (4 * n)
+        grads_tables = [None] * n_seg
+        da = g
+        for l in range(n - 1, -1, -1):
+            dz, dlw, dlb, dbias = _ln_act_backward(zs[l], da, lnw[l], lnb[l], ctx.acts[l], ctx.eps)
+            pdt = params[4 * l].dtype
+            grads_params[4 * l + 1] = dbias.to(pdt)
+            grads_params[4 * l + 2] = dlw.to(pdt)
+            grads_params[4 * l + 3] = dlb.to(pdt)
+            if l > 0:
+                a_prev = _ln_act_forward(zs[l - 1], lnw[l - 1], lnb[l - 1], ctx.acts[l - 1], ctx.eps)
+                grads_params[4 * l] = _wgrad(dz, a_prev).to(pdt)
+                del a_prev
+                da = dz @ W[l].detach().to(bf)                      # data gradient: bf16 library GEMM
+            else:
+                # first layer: gathered segments factor through S = segment_reduce(dz, idx) (see _FusedMLPTrain)
+                W0 = W[0].detach().to(bf)
+                dW = torch.empty(tuple(W[0].shape), dtype=torch.float32, device=dz.device)
+                col = 0
+                for s_i in range(n_seg):
+                    idx = indices[s_i]
+                    tab = tables[s_i].contiguous()
+                    w_s = int(tab.shape[1])
+                    W_s = W0[:, col:col + w_s]
+                    if idx is not None:
+                        S = _seg_reduce_wide(get_plan(idx, int(tab.shape[0])), dz)
+                        dW[:, col:col + w_s] = _wgrad(S, tab)
+                        if ctx.needs_input_grad[3 + s_i]:
+                            grads_tables[s_i] = S @ W_s
+                        del S
+                    else:
+                        dW[:, col:col + w_s] = _wgrad(dz, tab)
+                        if ctx.needs_input_grad[3 + s_i]:
+                            grads_tables[s_i] = dz @ W_s
+                    col += w_s
+                grads_params[0] = dW.to(pdt)
+        grad_skip = [g] if ctx.has_skip else []
+        return (None, None, None, *grads_tables, *grad_skip, *grads_params)

@@ -344,3 +344,34 @@ def knn_radius(query: torch.Tensor, points: torch.Tensor, k: int, radius, return
                                               _lib.ptr(ws), nbytes.value, _lib.current_stream(q.device)),
                    "hgnn_knn_radius_ws_f32")
     return (idx, d2) if return_dist2 else idx
+
+
+def wgrad_bf16(dz: torch.Tensor, rows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``dz^T @ rows`` for bf16 ``dz[M, Ho]`` and ``rows[M, Hi]`` (row-major, possibly column slices of wider
+    matrices) in fp32: the weight gradient of a Linear layer, by the hand-written split-K bf16-MFMA kernel
+    (``hgnn_wgrad_bf16``; deterministic).  ``out`` (fp32 [Ho, Hi], possibly a column slice) is written in place."""
+    _require_hip(dz, "dz", allow_bf16=True)
+    _require_hip(rows, "rows", allow_bf16=True)
+    if dz.dtype != torch.bfloat16 or rows.dtype != torch.bfloat16 or dz.dim() != 2 or rows.dim() != 2 \
+            or dz.shape[0] != rows.shape[0]:
+        raise RuntimeError("wgrad_bf16: bf16 dz[M, Ho] and rows[M, Hi] expected")
+    if dz.stride(1) != 1:
+        dz = dz.contiguous()
+    if rows.stride(1) != 1:
+        rows = rows.contiguous()
+    M, Ho, Hi = int(dz.shape[0]), int(dz.shape[1]), int(rows.shape[1])
+    if out is None:
+        out = torch.empty((Ho, Hi), dtype=torch.float32, device=dz.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (Ho, Hi) or out.stride(1) != 1:
+        raise RuntimeError("wgrad_bf16: out must be fp32 [Ho, Hi] with unit column stride")
+    lib = _lib.load()
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.hgnn_wgrad_workspace_bytes(M, Ho, Hi, ctypes.byref(nbytes)), "hgnn_wgrad_workspace_bytes")
+    ws = torch.empty(max(nbytes.value, 16), dtype=torch.uint8, device=dz.device)
+    lda = int(dz.stride(0)) if M > 1 else Ho
+    ldb = int(rows.stride(0)) if M > 1 else Hi
+    with torch.cuda.device(dz.device):
+        _lib.check(lib.hgnn_wgrad_bf16(_lib.ptr(dz), lda, _lib.ptr(rows), ldb, M, Ho, Hi,
+                                       ctypes.c_void_p(out.data_ptr()), int(out.stride(0)), _lib.ptr(ws), ws.numel(),
+                                       _lib.current_stream(dz.device)), "hgnn_wgrad_bf16")
+    return out

@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 14
+#define HGNN_ABI_VERSION 15
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -313,7 +313,9 @@ int hgnn_mlp_forward_bf16(const hgnn_mlp_desc* d, void* out, hgnn_stream_t strea
  * ORDER, natural feature order for every layer:
  *   element index = ((c * (F/16) + T) * 64 + lane) * 8 + i  holds  W[16T + lane%16][32c + 8(lane/16) + i]
  * (F = out features, c = 32-wide k-chunk, T = 16-feature tile, lane = 0..63, i = 0..7).
- * Supported: K -> 2L (-> 2L) -> L, LayerNorm on every layer, every segment a multiple of 128 wide. */
+ * Supported: K -> 2L (-> 2L) -> L, LayerNorm on every layer, every segment a multiple of 128 wide.
+ * save_pre[l] (optional) receives layer l's pre-LayerNorm rows as BF16 [M, width[l+1]] (8-byte aligned): the
+ * forward of the bf16 training path. */
 int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d);
 int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
 
@@ -332,6 +334,28 @@ int hgnn_ln_act_forward_f32(const float* z, int64_t M, int32_t W, const float* g
 int hgnn_ln_act_backward_f32(const float* z, const float* grad_out, int64_t M, int32_t W, const float* gamma,
                              const float* beta, int32_t act, float eps, float* grad_z,
                              float* partials /* [HGNN_LN_ACT_BLOCKS][3][W] */, hgnn_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * bf16 training path (BASELINE config 4 dtype): backward of the make_mlp Linear layers
+ * (Modules/utils.py:169-196 as instantiated at Modules/gnn_utils.py:22-41, :77-115) under the reference's
+ * autograd (edge_classifier_base.py:113-128 trains every configuration).
+ *
+ * hgnn_wgrad_bf16: weight gradient  out[ho, hi] = sum_m A[m, ho] * B[m, hi]  (A = dz [M, Ho], B = the layer's
+ *   input rows [M, Hi], both bf16 row-major with row strides lda / ldb in ELEMENTS (multiples of 8, so that a
+ *   column slice of a wider matrix can be passed); out fp32 [Ho, ldo]).  Hand-written split-K bf16-MFMA kernel,
+ *   fp32 accumulation, partial sums combined in slice order (deterministic, no atomics).  workspace: device
+ *   scratch of hgnn_wgrad_workspace_bytes(M, Ho, Hi) bytes.  Ho, Hi multiples of 8.
+ * hgnn_ln_act_{forward,backward}_bf16: hgnn_ln_act_*_f32 with bf16 rows (z, grad_out, out / grad_z); fp32
+ *   statistics and arithmetic, fp32 gamma / beta / partials.
+ */
+int hgnn_ln_act_forward_bf16(const void* z, int64_t M, int32_t W, const float* gamma, const float* beta,
+                             int32_t act, float eps, void* out, hgnn_stream_t stream);
+int hgnn_ln_act_backward_bf16(const void* z, const void* grad_out, int64_t M, int32_t W, const float* gamma,
+                              const float* beta, int32_t act, float eps, void* grad_z,
+                              float* partials /* [HGNN_LN_ACT_BLOCKS][3][W] */, hgnn_stream_t stream);
+int hgnn_wgrad_workspace_bytes(int64_t M, int32_t Ho, int32_t Hi, size_t* bytes);
+int hgnn_wgrad_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int32_t Ho, int32_t Hi,
+                    float* out, int64_t ldo, void* workspace, size_t workspace_bytes, hgnn_stream_t stream);
 
 #ifdef __cplusplus
 }
