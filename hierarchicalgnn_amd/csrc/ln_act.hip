@@ -15,11 +15,11 @@ namespace hgnn {
 
 constexpr int kLnActBlocks = HGNN_LN_ACT_BLOCKS;
 
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+// sum over the LPR lanes that own one row (LPR = 16: four rows per wave; LPR = 64: one 1024-wide row per wave)
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o);
     return v;
 }
 
@@ -60,47 +60,49 @@ __device__ __forceinline__ void st_row4(unsigned short* p, f32x4 v) {
     *(u16x4*)p = o;
 }
 
-template <int NV, bool BACKWARD, typename T>
+template <int NV, bool BACKWARD, typename T, int LPR = 16>
 __global__ __launch_bounds__(256) void k_ln_act(const T* __restrict__ z, const T* __restrict__ da,
                                                 long long M, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, int act, float eps,
                                                 T* __restrict__ out, float* __restrict__ partials) {
-    constexpr int W = NV * 64;
+    constexpr int W = NV * LPR * 4;
+    constexpr int RPW = 64 / LPR;      // rows per wave
+    constexpr int VS = LPR * 4;        // floats between a lane's consecutive vectors
     constexpr float inv_w = 1.0f / (float)W;
     __shared__ float red[BACKWARD ? 4 * 3 * W : 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int l16 = lane & 15;
-    const int rg = lane >> 4;  // row within the wave's group of 4
+    const int l16 = lane % LPR;  // this lane's 4-float column slot within a vector
+    const int rg = lane / LPR;   // row within the wave's group of RPW
     f32x4 gm[NV], bt[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        gm[v] = *(const f32x4*)(gamma + (v * 16 + l16) * 4);
-        bt[v] = *(const f32x4*)(beta + (v * 16 + l16) * 4);
+        gm[v] = *(const f32x4*)(gamma + (v * LPR + l16) * 4);
+        bt[v] = *(const f32x4*)(beta + (v * LPR + l16) * 4);
     }
     f32x4 s_dg[BACKWARD ? NV : 1], s_db[BACKWARD ? NV : 1], s_dz[BACKWARD ? NV : 1];
     if constexpr (BACKWARD) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) s_dg[v] = s_db[v] = s_dz[v] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (long long r0 = (long long)blockIdx.x * 16; r0 < M; r0 += (long long)gridDim.x * 16) {
-        const long long r = r0 + wave * 4 + rg;
+    for (long long r0 = (long long)blockIdx.x * (4 * RPW); r0 < M; r0 += (long long)gridDim.x * (4 * RPW)) {
+        const long long r = r0 + wave * RPW + rg;
         const bool valid = r < M;
         const size_t off = (size_t)(valid ? r : 0) * W + l16 * 4;
         f32x4 x[NV];
         float s = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            x[v] = ld_row4(z + off + v * 64);
+            x[v] = ld_row4(z + off + v * VS);
             s += (x[v].x + x[v].y) + (x[v].z + x[v].w);
         }
         f32x4 g[BACKWARD ? NV : 1];
         if constexpr (BACKWARD) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) g[v] = ld_row4(da + off + v * 64);
+            for (int v = 0; v < NV; ++v) g[v] = ld_row4(da + off + v * VS);
         }
-        const float mean = row16_sum(s) * inv_w;
+        const float mean = row_sum<LPR>(s) * inv_w;
         float q = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void k_ln_act(const T* __restrict__ z, const T
             q = fmaf(x[v].z, x[v].z, q);
             q = fmaf(x[v].w, x[v].w, q);
         }
-        const float rstd = 1.0f / sqrtf(row16_sum(q) * inv_w + eps);
+        const float rstd = 1.0f / sqrtf(row_sum<LPR>(q) * inv_w + eps);
         if constexpr (!BACKWARD) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void k_ln_act(const T* __restrict__ z, const T
                 o.y = act_apply(fmaf(x[v].y * rstd, gm[v].y, bt[v].y), act);
                 o.z = act_apply(fmaf(x[v].z * rstd, gm[v].z, bt[v].z), act);
                 o.w = act_apply(fmaf(x[v].w * rstd, gm[v].w, bt[v].w), act);
-                if (valid) st_row4(out + off + v * 64, o);
+                if (valid) st_row4(out + off + v * VS, o);
             }
         } else {
             // x <- xhat, g <- dy * gamma;  column sums of dy*xhat and dy;  row sums of g and g*xhat
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(256) void k_ln_act(const T* __restrict__ z, const T
                     sgx = fmaf(gg, xh, sgx);
                 }
             }
-            const float mg = row16_sum(sg) * inv_w;
-            const float mgx = row16_sum(sgx) * inv_w;
+            const float mg = row_sum<LPR>(sg) * inv_w;
+            const float mgx = row_sum<LPR>(sgx) * inv_w;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 f32x4 o;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void k_ln_act(const T* __restrict__ z, const T
                 o.z = rstd * (g[v].z - mg - x[v].z * mgx);
                 o.w = rstd * (g[v].w - mg - x[v].w * mgx);
                 if (valid) {
-                    st_row4(out + off + v * 64, o);
+                    st_row4(out + off + v * VS, o);
                     s_dz[v].x += o.x; s_dz[v].y += o.y; s_dz[v].z += o.z; s_dz[v].w += o.w;
                 }
             }
@@ -173,9 +175,9 @@ __global__ __launch_bounds__(256) void k_ln_act(const T* __restrict__ z, const T
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float t = p[k][c];
-                    t += __shfl_xor(t, 16);
-                    t += __shfl_xor(t, 32);
-                    if (rg == 0) red[(wave * 3 + k) * W + (v * 16 + l16) * 4 + c] = t;
+#pragma unroll
+                    for (int o = LPR; o < 64; o <<= 1) t += __shfl_xor(t, o);
+                    if (rg == 0) red[(wave * 3 + k) * W + (v * LPR + l16) * 4 + c] = t;
                 }
         }
         __syncthreads();
@@ -189,13 +191,18 @@ static int launch_ln_act(const T* z, const T* da, int64_t M, int W, const float*
                          int act, float eps, T* out, float* partials, hipStream_t s) {
     const unsigned grid = BACKWARD ? (unsigned)kLnActBlocks
                                    : (unsigned)(ceil_div(M, 16) < 4096 ? ceil_div(M, 16) : 4096);
+    if (W == 1024) {   // one row per wave (64 lanes x 4 vectors): the hidden width at latent 512
+        k_ln_act<4, BACKWARD, T, 64><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials);
+        HGNN_CHECK_HIP(hipGetLastError());
+        return HGNN_OK;
+    }
     switch (W / 64) {
         case 1: k_ln_act<1, BACKWARD, T><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
         case 2: k_ln_act<2, BACKWARD, T><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
         case 4: k_ln_act<4, BACKWARD, T><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
         case 8: k_ln_act<8, BACKWARD, T><<<grid, 256, 0, s>>>(z, da, M, gamma, beta, act, eps, out, partials); break;
         default:
-            set_error("hgnn_ln_act: width %d has no instantiation (64, 128, 256, 512)", W);
+            set_error("hgnn_ln_act: width %d has no instantiation (64, 128, 256, 512, 1024)", W);
             return HGNN_ERR_UNSUPPORTED;
     }
     HGNN_CHECK_HIP(hipGetLastError());
@@ -209,7 +216,8 @@ using namespace hgnn;
 static int check_ln_act(const void* z, int64_t M, int W, const void* gamma, const void* beta, int act,
                         const void* out, const char* who) {
     HGNN_REQUIRE(M >= 0, "%s: bad M", who);
-    HGNN_REQUIRE(W == 64 || W == 128 || W == 256 || W == 512, "%s: width must be 64, 128, 256 or 512 (got %d)", who, W);
+    HGNN_REQUIRE(W == 64 || W == 128 || W == 256 || W == 512 || W == 1024,
+                 "%s: width must be 64, 128, 256, 512 or 1024 (got %d)", who, W);
     HGNN_REQUIRE(act >= HGNN_ACT_NONE && act <= HGNN_ACT_RELU, "%s: unknown activation code %d", who, act);
     if (M == 0) return HGNN_OK;
     HGNN_REQUIRE(z != nullptr && gamma != nullptr && beta != nullptr && out != nullptr, "%s: NULL pointer", who);

@@ -149,9 +149,18 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long n = (long long)Ho * Hi;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += partial[(size_t)k * (size_t)n + i];   // slice order: deterministic
-    out[(size_t)(i / Hi) * (size_t)ldo + (i % Hi)] = s;
+    // four independent chains (slices k, k+1, k+2, k+3 mod 4) keep four loads in flight; the chains are then
+    // added in a fixed order: deterministic
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < slices; k += 4) {
+        s0 += partial[(size_t)k * (size_t)n + i];
+        s1 += partial[(size_t)(k + 1) * (size_t)n + i];
+        s2 += partial[(size_t)(k + 2) * (size_t)n + i];
+        s3 += partial[(size_t)(k + 3) * (size_t)n + i];
+    }
+    for (; k < slices; ++k) s0 += partial[(size_t)k * (size_t)n + i];
+    out[(size_t)(i / Hi) * (size_t)ldo + (i % Hi)] = (s0 + s1) + (s2 + s3);
 }
 
 struct Shape {
@@ -164,7 +173,9 @@ static Shape shape_for(long long M, int Ho, int Hi) {
     s.to = Ho > 128 ? 256 : 128;
     s.ti = (Ho > 128 && Hi > 128) ? 256 : 128;   // larger tiles = fewer re-reads of the 2M rows
     s.tiles = (int)(ceil_div(Ho, s.to) * ceil_div(Hi, s.ti));
-    long long want = ceil_div((long long)1024, s.tiles);     // ~4 workgroups per CU in total
+    // ~2 workgroups per CU in total: every slice costs a [Ho, Hi] fp32 partial that the reduce pass reads back
+    // (512 slices of a 512 x 256 gradient = 268 MB: the reduce took 184 us per call, 2/3 of the GEMM itself)
+    long long want = ceil_div((long long)512, s.tiles);
     long long max_slices = ceil_div(M, (long long)KT * 8);   // at least 8 steps per slice
     if (want > max_slices) want = max_slices;
     if (want < 1) want = 1;

@@ -528,7 +528,7 @@ class _FusedMLPTrain(torch.autograd.Function):
         lnb = [params[4 * l + 3] for l in range(n)]
         aten = torch.ops.aten
         g = grad_out.contiguous()
-        hip_rows = all(int(z.shape[1]) in (64, 128, 256, 512) for z in zs)
+        hip_rows = all(int(z.shape[1]) in (64, 128, 256, 512, 1024) for z in zs)
         ys, means, rstds, outs = [], [], [], []
         if hip_rows:
             # hidden activations a_l = act(LN(z_l)) for the weight gradients: one HIP pass per layer
@@ -615,7 +615,7 @@ def supported_train(net, segments, skip) -> bool:
         if not _train_bf16_enabled or not _wants_split(net, segments):
             return False
         layers = _parse(net)
-        if any(lin.out_features not in (64, 128, 256, 512) for lin, _, _ in layers):
+        if any(lin.out_features not in (64, 128, 256, 512, 1024) for lin, _, _ in layers):
             return False                              # widths of the bf16 LayerNorm / activation row kernels
         try:
             desc = _descriptor_bf16(net, segments, skip, split=True, dry=True)
@@ -713,6 +713,14 @@ class _FusedMLPTrainBf16(torch.autograd.Function):
         ctx.indices, ctx.has_skip, ctx.n = indices, has_skip, n
         ctx.acts = [int(d.act[l]) for l in range(n)]
         ctx.eps = float(d.ln_eps)
+        # skip is the same tensor as a direct (un-gathered) segment: its gradient is folded into that segment's
+        ctx.skip_seg = -1
+        if has_skip:
+            for s_i in range(n_seg):
+                t = tables[s_i]
+                if indices[s_i] is None and ctx.needs_input_grad[3 + s_i] and ctx.needs_input_grad[3 + n_seg] \
+                        and t.data_ptr() == skip.data_ptr() and t.shape == skip.shape and t.stride() == skip.stride():
+                    ctx.skip_seg = s_i
         ctx.save_for_backward(*tables, *params, *zs)
         return out
 
@@ -768,8 +776,13 @@ class _FusedMLPTrainBf16(torch.autograd.Function):
                     else:
                         dW[:, col:col + w_s] = _wgrad(dz, tab)
                         if ctx.needs_input_grad[3 + s_i]:
-                            grads_tables[s_i] = dz @ W_s
+                            if ctx.skip_seg == s_i:
+                                # the skip connection adds this very tensor (edges + MLP(..., edges)): its two
+                                # gradient contributions in ONE GEMM epilogue instead of a separate 3 GB add pass
+                                grads_tables[s_i] = torch.addmm(g, dz, W_s)
+                            else:
+                                grads_tables[s_i] = dz @ W_s
                     col += w_s
                 grads_params[0] = dW.to(pdt)
-        grad_skip = [g] if ctx.has_skip else []
+        grad_skip = [None if ctx.skip_seg >= 0 else g] if ctx.has_skip else []
         return (None, None, None, *grads_tables, *grad_skip, *grads_params)

@@ -327,7 +327,7 @@ int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hgnn_stream_t
  *              partials[b][0][c] = sum_r grad_y * xhat (dgamma), [b][1][c] = sum_r grad_y (dbeta),
  *              [b][2][c] = sum_r grad_z (gradient of the Linear's bias); the caller adds the
  *              HGNN_LN_ACT_BLOCKS partial rows (deterministic, no atomics).
- * W in {64, 128, 256, 512}; act = HGNN_ACT_*; exact-erf GELU as in the forward kernels. */
+ * W in {64, 128, 256, 512, 1024}; act = HGNN_ACT_*; exact-erf GELU as in the forward kernels. */
 #define HGNN_LN_ACT_BLOCKS 1024
 int hgnn_ln_act_forward_f32(const float* z, int64_t M, int32_t W, const float* gamma, const float* beta,
                             int32_t act, float eps, float* out, hgnn_stream_t stream);

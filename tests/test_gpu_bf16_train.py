@@ -40,7 +40,7 @@ def test_wgrad_bf16_column_slices():
     assert float(dW[:, :128].abs().max()) == 0.0 and float(dW[:, 256:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("W,act", [(128, 1), (256, 2), (512, 1), (64, 3)])
+@pytest.mark.parametrize("W,act", [(128, 1), (256, 2), (512, 1), (64, 3), (1024, 1), (1024, 2)])
 def test_ln_act_bf16_row_kernels(W, act):
     """bf16 rows, fp32 arithmetic: against fp32 autograd on the same (bf16-exact) inputs; the only differences
     are the final roundings to bf16 (2^-9 relative)"""
@@ -84,7 +84,7 @@ def _net(in_w, L, layers, out_act, seed):
 BF16_OUT, BF16_GRAD = 2e-2, 3e-2
 
 
-@pytest.mark.parametrize("L,layers", [(128, 2), (256, 2), (128, 3), (256, 3)])
+@pytest.mark.parametrize("L,layers", [(128, 2), (256, 2), (128, 3), (256, 3), (512, 2), (512, 3)])
 def test_fused_train_bf16_matches_fp32_autograd(L, layers):
     from hierarchicalgnn_amd import fused, mlp
     g = torch.Generator().manual_seed(L + layers)

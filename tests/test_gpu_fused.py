@@ -217,7 +217,7 @@ def test_fused_train_backward_matches_autograd(L, layers):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL
 
 
-@pytest.mark.parametrize("W", [64, 128, 256, 512])
+@pytest.mark.parametrize("W", [64, 128, 256, 512, 1024])
 @pytest.mark.parametrize("act", [0, 1, 2, 3])
 def test_ln_act_row_kernels_against_autograd(W, act):
     """hgnn_ln_act_forward_f32 / hgnn_ln_act_backward_f32 (one make_mlp layer's LayerNorm + activation and
