@@ -12,7 +12,8 @@ import os
 from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhgnn_hip.so")
+# HGNN_LIB: A/B measurements of two builds of the SAME sources with different tuning constants (tools/); never a fallback
+LIB_PATH = os.environ.get("HGNN_LIB") or os.path.join(_HERE, "csrc", "libhgnn_hip.so")
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5

@@ -77,7 +77,7 @@ __device__ __forceinline__ float act_t(float x, int act) {
 
 template <int NT>
 struct Ring {
-    static constexpr int R = NT > 8 ? NT : 8;  // fragments in flight per wave
+    static constexpr int R = NT > 8 ? NT : 8;  // fragments in flight per wave (16 measured: L=256 2.89 vs 2.79 ms (12 spilled registers), L=128 1.29 vs 1.08 ms (occupancy 3 -> 2), L=512 8.44 vs 8.52 ms: the ring depth is not what parks the waves)
     static constexpr int CPI = R / NT;         // = chunks the ring runs ahead
 };
 
@@ -101,7 +101,7 @@ __device__ __forceinline__ void ring_fill(u16x8 (&w)[Ring<NT>::R], const u16x8* 
 template <int NT, int RS, int VAR, int NW, int NJ>
 __device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][NJ], u16x8 (&w)[Ring<NT>::R],
                                          const u16x8* __restrict__ wp, int gc0, int total,
-                                         const char* bsrc, int n, int ablate) {
+                                         const char* bsrc, int kx, int n, int ablate) {
     constexpr int CPI = Ring<NT>::CPI;
     constexpr int U = CPI < 2 ? 2 : CPI;
     // NJ = 4: the next chunk's B fragments are read into a second register set at the start of the
@@ -110,7 +110,12 @@ __device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][NJ], u16x8 (&w)[Ring<N
     constexpr bool INPLACE = NJ > 4;
     u16x8 b[INPLACE ? 1 : 2][NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) b[0][j] = *(const u16x8*)(bsrc + j * 16 * RS);
+    // LDS rows are XOR-swizzled in 16-byte pieces: logical piece q of row r sits at piece q ^ (r & 15).  A lane
+    // reads piece 4c + g of row 16j + e, i.e. physical piece (4 (c ^ kx)) + (g ^ (e & 3)) with kx = e >> 2: `bsrc`
+    // already carries the (g ^ (e & 3)) part, the chunk index is XORed here.  Every 16-lane group of ds_read_b128
+    // ({0-3,12-15,20-27}, ...) then touches 16 distinct 16-byte slots of the 64 banks: conflict-free (with the
+    // former +16-byte row padding the groups' lanes (e=11,g=1) and (e=12,g=0) shared a slot: 2-way).
+    for (int j = 0; j < NJ; ++j) b[0][j] = *(const u16x8*)(bsrc + j * 16 * RS + (kx << 6));
     for (int c = 0; c < n; c += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -127,8 +132,9 @@ __device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][NJ], u16x8 (&w)[Ring<N
             constexpr int cur = INPLACE ? 0 : 0;
             const int bi = INPLACE ? 0 : (u & 1);
             if constexpr (!INPLACE) {
+                const int cx = (cn ^ kx) << 6;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) b[(u + 1) & 1][j] = *(const u16x8*)(bsrc + j * 16 * RS + cn * 64);
+                for (int j = 0; j < NJ; ++j) b[(u + 1) & 1][j] = *(const u16x8*)(bsrc + j * 16 * RS + cx);
                 // pin the issue order (hipcc otherwise sinks every load to just before its first use,
                 // i.e. an L2 round trip behind 4 MFMAs): the next chunk's B reads first, then per tile
                 // NJ MFMAs followed by the ring refill that runs 8 fragments ahead
@@ -146,7 +152,7 @@ __device__ __forceinline__ void gemm_lds(f32x4 (&acc)[NT][NJ], u16x8 (&w)[Ring<N
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(w[slot]), as_bf16(b[bi][j]),
                                                                         acc[t][j], 0, 0, 0);
                     if (INPLACE && t == NT - 1) {
-                        b[0][j] = *(const u16x8*)(bsrc + j * 16 * RS + cn * 64);
+                        b[0][j] = *(const u16x8*)(bsrc + j * 16 * RS + ((cn ^ kx) << 6));
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
@@ -235,11 +241,32 @@ __device__ __forceinline__ void init_bias(f32x4 (&acc)[NT][NJ], const float* __r
     }
 }
 
-// activated tile -> bf16 hidden rows in LDS (row = edge, stride HRS bytes)
-template <int NT, int HRS, int NJ>
-__device__ __forceinline__ void write_hidden(const f32x4 (&acc)[NT][NJ], char* hid_lane) {
+// activated tile -> bf16 hidden rows in LDS (row = edge, stride HRS bytes, 16-byte pieces XOR-swizzled with the
+// row: see gemm_lds).  `row0` = this lane's row 0 of the tile (smem + ei * HRS); the lane's 4 features of tile t are
+// the (g & 1) half of logical piece pbase + 2 t + (g >> 1)
+template <int NT, int HRS, int NJ, bool SWZ>
+__device__ __forceinline__ void write_hidden(const f32x4 (&acc)[NT][NJ], char* row0, int pbase, int ei, int g) {
+    if constexpr (!SWZ) {
+        // padded rows (narrow shapes): one precomputed lane pointer, immediate offsets -- this variant sits exactly
+        // on the 168-register boundary of 3 waves per SIMD
+        char* hid_lane = row0 + ((pbase << 4) + (g << 3));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                u16x4 o;
+                o[0] = bf16_bits(acc[t][j].x);
+                o[1] = bf16_bits(acc[t][j].y);
+                o[2] = bf16_bits(acc[t][j].z);
+                o[3] = bf16_bits(acc[t][j].w);
+                *(u16x4*)(hid_lane + j * 16 * HRS + t * 32) = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        const int off = (((pbase + 2 * t + (g >> 1)) ^ ei) << 4) + ((g & 1) << 3);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             u16x4 o;
@@ -247,7 +274,7 @@ __device__ __forceinline__ void write_hidden(const f32x4 (&acc)[NT][NJ], char* h
             o[1] = bf16_bits(acc[t][j].y);
             o[2] = bf16_bits(acc[t][j].z);
             o[3] = bf16_bits(acc[t][j].w);
-            *(u16x4*)(hid_lane + j * 16 * HRS + t * 32) = o;
+            *(u16x4*)(row0 + j * 16 * HRS + off) = o;
         }
     }
 }
@@ -314,8 +341,15 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
     constexpr int TE = 16 * NJ;              // rows per workgroup
     constexpr int NTHR = NW * 64;
     constexpr int NC2 = NT1 * NW / 2;        // k-chunks of the hidden layers (width / 32)
-    constexpr int HRS = NT1 * NW * 32 + 16;  // hidden row stride (bytes): +16 spreads rows over the banks
-    constexpr int PRS = PK * 2 + 16;        // panel row stride
+    // Hidden width >= 512 (L >= 256): rows of whole 256-byte bank rows, 16-byte pieces XOR-swizzled with the row
+    // (gemm_lds): SQ_LDS_BANK_CONFLICT 9.5 % of SQ_LDS_IDX_ACTIVE instead of 39 % (profiles/r02_edge_mlp_bf16_split_pmc.txt).
+    // The kernel time does not move (2.75-2.83 ms at L=256, 8.6 ms at L=512: the LDS array is 14 % busy, it was never
+    // the bound).  The L=128 variant sits exactly on the 168-register boundary of 3 waves per SIMD and the swizzled
+    // addressing needs one register more (occupancy 3 -> 2: 1.30 vs 1.08 ms), so the narrow shape keeps the
+    // +16-byte row padding.
+    constexpr bool SWZ = NT1 * NW >= 32;
+    constexpr int HRS = NT1 * NW * 32 + (SWZ ? 0 : 16);  // hidden row stride (bytes)
+    constexpr int PRS = PK * 2 + (SWZ ? 0 : 16);         // panel row stride
     constexpr int PANEL = TE * PRS;
     constexpr int REGION = cmax(TE * HRS, 2 * PANEL);  // the panels alias the hidden rows
     constexpr int CPP = PK / 32;                      // k-chunks per panel
@@ -368,7 +402,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
     auto store_panel = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NP; ++i)
-            *(u16x8*)(smem + buf * PANEL + (i * RPP + prow) * PRS + pcol * 16) = st[i];
+            *(u16x8*)(smem + buf * PANEL + (i * RPP + prow) * PRS + ((pcol ^ (SWZ ? (prow & 15) : 0)) << 4)) = st[i];
     };
 
     // ---------------- layer 1: B = input panels
@@ -406,11 +440,12 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
         ring_fill<NT1, NW>(w, wp, total);
         store_panel(0);
         __syncthreads();
-        const char* blane = smem + ei * PRS + g * 16;
+        const char* blane = smem + ei * PRS + ((g ^ (SWZ ? (ei & 3) : 0)) << 4);
+        const int kx = SWZ ? (ei >> 2) : 0;
         for (int p = 0; p < np; ++p) {
             const bool more = p + 1 < np && !(a.ablate & 4);
             if (more) load_panel();
-            gemm_lds<NT1, PRS, VAR, NW, NJ>(acc1, w, wp, p * CPP, total, blane + (p & 1) * PANEL, CPP, a.ablate);
+            gemm_lds<NT1, PRS, VAR, NW, NJ>(acc1, w, wp, p * CPP, total, blane + (p & 1) * PANEL, kx, CPP, a.ablate);
             if (more) store_panel((p + 1) & 1);
             if (!(a.ablate & 8)) __syncthreads();
         }
@@ -419,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
     layernorm_act<NT1, ACT_H, NW, NJ>(acc1, a.lnw[0] + wave * NT1 * 16 + 4 * g, a.lnb[0] + wave * NT1 * 16 + 4 * g, a.act[0],
                               a.eps, red, wave, ei, g, a.ablate);
     // (the barrier inside layernorm_act also means: every wave is done reading the panels)
-    write_hidden<NT1, HRS, NJ>(acc1, smem + ei * HRS + (wave * NT1 * 16 + 4 * g) * 2);
+    write_hidden<NT1, HRS, NJ, SWZ>(acc1, smem + ei * HRS, 2 * wave * NT1, ei, g);
     __syncthreads();
 
     // ---------------- layer 2: B = hidden rows
@@ -429,7 +464,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
         const u16x8* wp = (const u16x8*)a.W[1] + (size_t)(wave * NT2) * 64 + lane;
         u16x8 w[Ring<NT2>::R];
         ring_fill<NT2, NW>(w, wp, NC2);
-        gemm_lds<NT2, HRS, VAR, NW, NJ>(acc2, w, wp, 0, NC2, smem + ei * HRS + g * 16, NC2, a.ablate);
+        gemm_lds<NT2, HRS, VAR, NW, NJ>(acc2, w, wp, 0, NC2, smem + ei * HRS + ((g ^ (SWZ ? (ei & 3) : 0)) << 4), SWZ ? (ei >> 2) : 0, NC2, a.ablate);
     }
     dump_pre<NT2, NW, NJ>(acc2, a.save_pre[1], a.M, e0, wave, ei, g);
     if constexpr (NT3 == 0) {
@@ -440,7 +475,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
         layernorm_act<NT2, ACT_H, NW, NJ>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
                                   a.act[1], a.eps, red, wave, ei, g, a.ablate);
         // in place: the barrier inside layernorm_act came after every wave's layer-2 reads
-        write_hidden<NT2, HRS, NJ>(acc2, smem + ei * HRS + (wave * NT2 * 16 + 4 * g) * 2);
+        write_hidden<NT2, HRS, NJ, SWZ>(acc2, smem + ei * HRS, 2 * wave * NT2, ei, g);
         __syncthreads();
         f32x4 acc3[NT3][NJ];
         init_bias<NT3, NJ>(acc3, a.b[2] + wave * NT3 * 16 + 4 * g);
@@ -448,7 +483,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
             const u16x8* wp = (const u16x8*)a.W[2] + (size_t)(wave * NT3) * 64 + lane;
             u16x8 w[Ring<NT3>::R];
             ring_fill<NT3, NW>(w, wp, NC2);
-            gemm_lds<NT3, HRS, VAR, NW, NJ>(acc3, w, wp, 0, NC2, smem + ei * HRS + g * 16, NC2, a.ablate);
+            gemm_lds<NT3, HRS, VAR, NW, NJ>(acc3, w, wp, 0, NC2, smem + ei * HRS + ((g ^ (SWZ ? (ei & 3) : 0)) << 4), SWZ ? (ei >> 2) : 0, NC2, a.ablate);
         }
         dump_pre<NT3, NW, NJ>(acc3, a.save_pre[2], a.M, e0, wave, ei, g);
         layernorm_act<NT3, ACT_O, NW, NJ>(acc3, a.lnw[2] + wave * NT3 * 16 + 4 * g, a.lnb[2] + wave * NT3 * 16 + 4 * g,
@@ -461,8 +496,9 @@ template <int NT1, int NT2, int NT3, int MINB, int ACT_H, int ACT_O, int VAR, in
 static int launch_act(const Args& a, hipStream_t s) {
     constexpr int PK = 128;
     constexpr int TE = 16 * NJ;
-    constexpr int HRS = NT1 * NW * 32 + 16;
-    constexpr int PRS = PK * 2 + 16;
+    constexpr bool SWZ = NT1 * NW >= 32;
+    constexpr int HRS = NT1 * NW * 32 + (SWZ ? 0 : 16);
+    constexpr int PRS = PK * 2 + (SWZ ? 0 : 16);
     const size_t lds_bytes = (size_t)cmax(TE * HRS, 2 * TE * PRS) + NW * TE * 2 * sizeof(float);
     const unsigned grid = (unsigned)ceil_div(a.M, TE);
     auto kern = k_mlp_bf16_split<NT1, NT2, NT3, PK, ACT_H, ACT_O, MINB, VAR, NW, NJ>;

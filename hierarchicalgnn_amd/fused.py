@@ -629,7 +629,9 @@ def supported_train(net, segments, skip) -> bool:
     if desc is None:
         return False
     d = desc[0]
-    if int(d.w0_cols) != 0 or int(d.w_last_rows) != 0:
+    # heads / narrow encoders (zero-padded last layer) have no dumps; the small-K encoders (w0_cols = 16: the
+    # kernel-side zero padding of W[0]) do -- their backward uses the unpadded parameters
+    if int(d.w_last_rows) != 0:
         return False
     return bool(_lib.load().hgnn_mlp_supported(ctypes.byref(d)))
 

@@ -34,6 +34,10 @@ def _head_input(t, hparams):
     fp32 kernel and, in bf16 mode, the library path runs the head's wide GEMMs in bf16 (autocast)"""
     if t.dtype == torch.float32 or int(hparams["latent"]) > 256:
         return t
+    if torch.is_grad_enabled() and t.requires_grad:
+        # training in bf16 mode: there is no differentiable fused head, so the head's wide GEMMs (1 TFLOP at
+        # latent 256, E = 1M) would be fp32 library GEMMs; keep the rows in bf16 instead (library autocast)
+        return t
     return t.float()
 
 

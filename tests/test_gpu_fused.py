@@ -397,3 +397,44 @@ def test_bc_forward_latent256_has_no_library_mlp():
     expected = 2 + 2 * 6 + 1 + 2 + 4 * 6 + 1        # encoders, IGNN cells, emb head, super encoders, HGNN cells, head
     assert calls["n"] == expected
     assert fused.stats["fused_calls"] - n0 == expected
+
+
+@pytest.mark.parametrize("L,kind", [(64, "node_enc"), (128, "edge_enc"), (256, "edge_enc")])
+def test_fused_train_small_k_encoders(L, kind):
+    """the node / edge encoders (K = 3 / 6, IN.py:84-85) on the differentiable fused path: gradients w.r.t. the
+    hit coordinates (the reference sets x.requires_grad, IN.py:82) and the weights against plain autograd"""
+    from hierarchicalgnn_amd import fused, make_mlp, mlp
+    g = torch.Generator().manual_seed(L + 11)
+    N, M = 400, 2500
+    x = (torch.rand(N, 3, generator=g) * 2 - 1).cuda()
+    i0 = torch.randint(0, N, (M,), generator=g).cuda()
+    i1 = torch.randint(0, N, (M,), generator=g).cuda()
+    torch.manual_seed(L)
+    if kind == "edge_enc":
+        net = make_mlp(6, 2 * L, L, 2, layer_norm=True, output_activation="GELU", hidden_activation="GELU").cuda()
+        rows = M
+    else:
+        net = make_mlp(3, 2 * L, L, 3, layer_norm=True, output_activation="GELU", hidden_activation="GELU").cuda()
+        rows = N
+    r = torch.randn(rows, L, generator=g).cuda()
+
+    def run(use_fused):
+        for p in net.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        segs = [(xx, i0), (xx, i1)] if kind == "edge_enc" else [(xx, None)]
+        if use_fused:
+            n0 = fused.stats["fused_train_calls"]
+            out = mlp.concat_mlp(net, segs)
+            assert fused.stats["fused_train_calls"] == n0 + 1
+        else:
+            out = net(torch.cat([t if i is None else t[i] for t, i in segs], dim=1))
+        (out * r).sum().backward()
+        return out.detach(), xx.grad, [p.grad.clone() for p in net.parameters()]
+
+    o_ref, gx_ref, gp_ref = run(False)
+    o, gx, gp = run(True)
+    assert rel_err(o.cpu().numpy(), o_ref.cpu().numpy()) <= TOL
+    assert rel_err(gx.cpu().numpy(), gx_ref.cpu().numpy()) <= TOL
+    for (name, _), a, b in zip(net.named_parameters(), gp, gp_ref):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL, name
