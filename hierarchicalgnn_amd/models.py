@@ -188,7 +188,7 @@ class HierarchicalGNNBlock(nn.Module):
         return gmm_edge_clustering(embeddings, graph, self.score_cut, self.hparams, self.training,
                                    return_count=return_count)
 
-    def hierarchy_from_clusters(self, embeddings, clusters, n_clusters=None):
+    def hierarchy_from_clusters(self, embeddings, clusters, n_clusters=None, graphs=None):
         """HGNN_GMM.py:251-260 given the cluster label of every hit (-1 = unclustered): centroids
         (scatter_mean, K8), L2-normalise, kNN super graph (symmetrised, sigmoid weights) and
         bipartite graph (exp weights), both mean-normalised.  ``n_clusters`` (known from the clustering
@@ -202,6 +202,14 @@ class HierarchicalGNNBlock(nn.Module):
         counts = scatter_add(torch.ones(embeddings.shape[0], 1, device=embeddings.device), lab, dim=0,
                              dim_size=n_clusters + 1, validate=False)[:n_clusters].clamp_(min=1)
         means = nn.functional.normalize(sums / counts)
+        if graphs is not None:
+            # a caller-supplied topology (bipartite_graph, super_graph): only the differentiable attention
+            # weights are evaluated on it (gnn_utils.py:208-216)
+            bip_graph, super_graph = graphs
+            super_w = self.super_graph_construction.edge_weights(means, means, super_graph, norm=True)
+            bip_w, bip_logits = self.bipartite_graph_construction.edge_weights(embeddings, means, bip_graph, norm=True,
+                                                                              logits=True)
+            return means, bip_graph, bip_w, super_graph, super_w, bip_logits
         super_graph, super_w = self.super_graph_construction(
             means, means, sym=True, norm=True, k=self.hparams["supergraph_sparsity"])
         bip_graph, bip_w, bip_logits = self.bipartite_graph_construction(

@@ -225,3 +225,69 @@ def test_config5_full_pileup_k1_properties():
     assert torch.equal(out, out2)
     out3 = H.scatter_add(src * 2.0, graph[1], dim=0, dim_size=N)
     assert torch.equal(out3, out * 2.0)                         # scaling by 2 is exact in fp32
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_config3_config4_bc_training_step_matches_the_library_path(dtype):
+    """a BC-HGNN-GMM TRAINING step (configs 3 / 4 train under the reference's autograd,
+    bipartite_classification_base.py:194-200): IGNN block -> hierarchy (clusters fixed, kNN graphs + differentiable
+    attention weights rebuilt) -> K5 pooling -> HGNN cells -> bipartite head, loss on scores and embeddings.  Every
+    parameter that the library path (HIP gathers + ATen / rocBLAS autograd, fused kernels off) gives a gradient
+    gets the same gradient from the fused differentiable kernels."""
+    from hierarchicalgnn_amd import fused, synth
+    from hierarchicalgnn_amd.models import BC_MessagePassing
+    L = 128
+    hp = dict(spatial_channels=3, latent=L, hidden="ratio", hidden_ratio=2, emb_dim=8, n_interaction_graph_iters=2,
+              n_hierarchical_graph_iters=2, nb_node_layer=3, nb_edge_layer=2, output_layers=3,
+              hidden_output_activation="Tanh", hidden_activation="GELU", layernorm=True, share_weight=False,
+              bipartitegraph_sparsity=5, supergraph_sparsity=10, min_cluster_size=3, cluster_granularity=5)
+    if dtype == "bf16":
+        hp["feature_dtype"] = "bf16"
+    model = BC_MessagePassing(hp)
+    seeded.fill_parameters(model, 31)
+    model = model.cuda().eval()                       # eval: frozen BatchNorm statistics / kNN radius (pure function)
+    model.hgnn_block.super_graph_construction.knn_radius.fill_(2.0)
+    model.hgnn_block.bipartite_graph_construction.knn_radius.fill_(2.0)
+    x, ei = synth.trackml_event(4000, 24000, seed=11)
+    x, ei = x.cuda(), ei.cuda()
+    gen = torch.Generator().manual_seed(5)
+    clusters = torch.randint(-1, 150, (4000,), generator=gen).cuda()      # a fixed hierarchy decision
+    clusters[:150] = torch.arange(150).cuda()
+
+    with torch.no_grad():                             # the discrete part of the hierarchy, decided once
+        _, emb0, _, _, _ = model.embed(x, ei)
+        _, bg0, _, sg0, _, _ = model.hgnn_block.hierarchy_from_clusters(emb0, clusters, 150)
+
+    def step(use_fused):
+        fused.set_enabled(use_fused)
+        try:
+            for p in model.parameters():
+                p.grad = None
+            xx = x.clone()
+            directed, emb, nodes, edges, _ = model.embed(xx, ei)
+            means, bg, bw, sg, sw, _ = model.hgnn_block.hierarchy_from_clusters(emb, clusters, 150, graphs=(bg0, sg0))
+            n_out, sn_out, _, _ = model.hgnn_block(nodes, edges, directed, means, bg, bw, sg, sw)
+            scores = model.score(n_out, sn_out, bg)
+            r = torch.randn(scores.shape[0], generator=torch.Generator().manual_seed(9)).cuda()
+            loss = (scores * r).sum() + 0.1 * (emb * emb.roll(1, 0)).sum()
+            loss.backward()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            return bg, scores.detach(), grads, xx.grad
+        finally:
+            fused.set_enabled(True)
+
+    n0 = fused.stats["fused_train_calls"]
+    bg_f, s_f, g_f, gx_f = step(True)
+    assert fused.stats["fused_train_calls"] - n0 >= 2 * 2 + 4 * 2         # every cell MLP differentiable-fused
+    bg_l, s_l, g_l, gx_l = step(False)
+    assert torch.equal(bg_f, bg_l) and torch.equal(bg_f, bg0)            # the same kNN graphs on both paths
+    tol_s, tol_g = (1e-4, 2e-3) if dtype == "fp32" else (2e-2, 6e-2)      # bf16: both paths round rows to 8 bits
+    assert float((s_f - s_l).abs().max()) <= tol_s
+    assert set(g_f) == set(g_l) and len(g_f) > 100
+    for k in g_l:
+        ref = g_l[k].float().cpu().numpy()
+        got = g_f[k].float().cpu().numpy()
+        # normwise, with an absolute floor: BatchNorm1d(1)'s affine sits in front of a mean-normalised weight
+        # (gnn_utils.py:213), its true gradient is ~0 and what is left is fp32 noise of order 1e-6
+        assert np.abs(got - ref).max() <= tol_g * np.abs(ref).max() + 1e-5, k
+    assert rel_err(gx_f.cpu().numpy(), gx_l.cpu().numpy()) <= tol_g
