@@ -23,20 +23,6 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
-// exact-GELU derivative: Phi(y) + y * phi(y)
-__device__ __forceinline__ float act_grad(float y, float a, int act) {
-    switch (act) {
-        case HGNN_ACT_GELU: {
-            const float cdf = 0.5f * (1.0f + fast_erf(y * 0.70710678118654752440f));
-            const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * y * y);
-            return fmaf(y, pdf, cdf);
-        }
-        case HGNN_ACT_TANH: return fmaf(-a, a, 1.0f);
-        case HGNN_ACT_RELU: return y > 0.f ? 1.0f : 0.f;
-        default: return 1.0f;
-    }
-}
-
 // rows in fp32 (T = float) or bf16 (T = unsigned short: the training path of BASELINE config 4; statistics and
 // all arithmetic stay fp32, one rounding per stored element)
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));

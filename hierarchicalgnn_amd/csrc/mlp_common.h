@@ -41,6 +41,20 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     }
 }
 
+// exact-GELU derivative: Phi(y) + y * phi(y)
+__device__ __forceinline__ float act_grad(float y, float a, int act) {
+    switch (act) {
+        case HGNN_ACT_GELU: {
+            const float cdf = 0.5f * (1.0f + fast_erf(y * 0.70710678118654752440f));
+            const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * y * y);
+            return fmaf(y, pdf, cdf);
+        }
+        case HGNN_ACT_TANH: return fmaf(-a, a, 1.0f);
+        case HGNN_ACT_RELU: return y > 0.f ? 1.0f : 0.f;
+        default: return 1.0f;
+    }
+}
+
 // Weight staging.  W[NF][Kdim] row-major (torch Linear.weight); chunk = columns [k0, k0+16).
 // One 1-KiB LDS-DMA piece covers 16 rows: lane (i = lane&15, g = lane>>4) fetches
 // W[16p+i][k0+4g .. +3] and the DMA lands it at lane*16 bytes, i.e. the piece is stored in exactly

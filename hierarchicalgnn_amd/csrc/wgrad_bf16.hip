@@ -45,7 +45,7 @@ template <int TO, int TI, int WO, int WI>
 __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned short* __restrict__ A, long long lda,
                                                              const unsigned short* __restrict__ B, long long ldb,
                                                              long long M, int Ho, int Hi, float* __restrict__ partial,
-                                                             long long rows_per_slice) {
+                                                             long long rows_per_slice, float* __restrict__ partial_cs) {
     constexpr int NTHR = WO * WI * 64;
     constexpr int SA = TO * 2 + 32, SB = TI * 2 + 32;  // LDS row strides in bytes
     constexpr int PA = TO / 8, PB = TI / 8;            // 16-byte pieces per tile row
@@ -103,6 +103,14 @@ __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned shor
     for (int fo = 0; fo < FO; ++fo)
 #pragma unroll
         for (int fi = 0; fi < FI; ++fi) acc[fo][fi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // optional column sums of A (= the Linear's bias gradient, sum_m dz[m][ho]): one more MFMA per A fragment against
+    // an all-ones operand, by the waves of the first hi-tile column only (wave-uniform condition)
+    const bool do_cs = partial_cs != nullptr && hi0 == 0 && wi == 0;
+    f32x4 acs[FO];
+#pragma unroll
+    for (int fo = 0; fo < FO; ++fo) acs[fo] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f,
+                         (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
 
     if (steps > 0) {
         load(0);
@@ -123,6 +131,7 @@ __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned shor
 #pragma unroll
             for (int fi = 0; fi < FI; ++fi)
                 acc[fo][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[fi], acc[fo][fi], 0, 0, 0);
+            if (do_cs) acs[fo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, acs[fo], 0, 0, 0);
         }
         if (more) store((s + 1) & 1);
         __syncthreads();
@@ -142,12 +151,27 @@ __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned shor
             }
         }
     }
+    if (do_cs && (lane & 15) == 0) {   // every column of the all-ones product holds the same sums: take column 0
+#pragma unroll
+        for (int fo = 0; fo < FO; ++fo) {
+            const int ho = ho0 + wo * (TO / WO) + fo * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ho + r < Ho) partial_cs[(size_t)blockIdx.y * (size_t)Ho + ho + r] = acs[fo][r];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int slices, int Ho, int Hi,
-                                                      float* __restrict__ out, long long ldo) {
+                                                      float* __restrict__ out, long long ldo,
+                                                      const float* __restrict__ partial_cs, float* __restrict__ colsum) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long n = (long long)Ho * Hi;
+    if (colsum != nullptr && i < Ho) {
+        float s = 0.f;
+        for (int k = 0; k < slices; ++k) s += partial_cs[(size_t)k * (size_t)Ho + i];   // slice order
+        colsum[i] = s;
+    }
     if (i >= n) return;
     // four independent chains (slices k, k+1, k+2, k+3 mod 4) keep four loads in flight; the chains are then
     // added in a fixed order: deterministic
@@ -193,13 +217,13 @@ using namespace hgnn;
 extern "C" int hgnn_wgrad_workspace_bytes(int64_t M, int32_t Ho, int32_t Hi, size_t* bytes) {
     HGNN_REQUIRE(bytes != nullptr && M >= 0 && Ho > 0 && Hi > 0, "hgnn_wgrad_workspace_bytes: bad argument");
     const wg::Shape s = wg::shape_for(M, Ho, Hi);
-    *bytes = (size_t)s.slices * (size_t)Ho * (size_t)Hi * sizeof(float);
+    *bytes = (size_t)s.slices * ((size_t)Ho * (size_t)Hi + (size_t)Ho) * sizeof(float);
     return HGNN_OK;
 }
 
 extern "C" int hgnn_wgrad_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int32_t Ho,
-                               int32_t Hi, float* out, int64_t ldo, void* workspace, size_t workspace_bytes,
-                               hgnn_stream_t stream_) {
+                               int32_t Hi, float* out, int64_t ldo, float* colsum, void* workspace,
+                               size_t workspace_bytes, hgnn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     HGNN_REQUIRE(M >= 0 && Ho > 0 && Hi > 0 && Ho % 8 == 0 && Hi % 8 == 0,
                  "hgnn_wgrad_bf16: Ho and Hi must be positive multiples of 8 (got %d, %d)", Ho, Hi);
@@ -209,10 +233,11 @@ extern "C" int hgnn_wgrad_bf16(const void* A, int64_t lda, const void* B, int64_
     HGNN_REQUIRE(M == 0 || (A != nullptr && B != nullptr && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0),
                  "hgnn_wgrad_bf16: operands are NULL or not 16-byte aligned");
     const wg::Shape s = wg::shape_for(M, Ho, Hi);
-    const size_t need = (size_t)s.slices * (size_t)Ho * (size_t)Hi * sizeof(float);
+    const size_t need = (size_t)s.slices * ((size_t)Ho * (size_t)Hi + (size_t)Ho) * sizeof(float);
     HGNN_REQUIRE(workspace != nullptr && workspace_bytes >= need && (uintptr_t)workspace % 16 == 0,
                  "hgnn_wgrad_bf16: workspace too small (%zu < %zu) or unaligned", workspace_bytes, need);
     float* partial = (float*)workspace;
+    float* partial_cs = colsum != nullptr ? partial + (size_t)s.slices * (size_t)Ho * (size_t)Hi : nullptr;
     const dim3 grid((unsigned)s.tiles, (unsigned)s.slices);
     if (s.to == 256 && s.ti == 256) {
         constexpr int TO = 256, TI = 256;
@@ -220,19 +245,20 @@ extern "C" int hgnn_wgrad_bf16(const void* A, int64_t lda, const void* B, int64_
         auto kern = wg::k_wgrad_bf16<TO, TI, 2, 4>;
         HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, 512, lds, stream>>>((const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, Ho, Hi, partial,
-                                         s.rows_per_slice);
+                                         s.rows_per_slice, partial_cs);
     } else if (s.to == 256) {
         constexpr int TO = 256, TI = 128;
         const size_t lds = 2 * wg::KT * (size_t)((TO * 2 + 32) + (TI * 2 + 32));
         wg::k_wgrad_bf16<TO, TI, 4, 2><<<grid, 512, lds, stream>>>((const unsigned short*)A, lda, (const unsigned short*)B,
-                                                                   ldb, M, Ho, Hi, partial, s.rows_per_slice);
+                                                                   ldb, M, Ho, Hi, partial, s.rows_per_slice, partial_cs);
     } else {
         constexpr int TO = 128, TI = 128;
         const size_t lds = 2 * wg::KT * (size_t)((TO * 2 + 32) + (TI * 2 + 32));
         wg::k_wgrad_bf16<TO, TI, 2, 2><<<grid, 256, lds, stream>>>((const unsigned short*)A, lda, (const unsigned short*)B,
-                                                                   ldb, M, Ho, Hi, partial, s.rows_per_slice);
+                                                                   ldb, M, Ho, Hi, partial, s.rows_per_slice, partial_cs);
     }
-    wg::k_wgrad_reduce<<<(unsigned)ceil_div((int64_t)Ho * Hi, 256), 256, 0, stream>>>(partial, s.slices, Ho, Hi, out, ldo);
+    wg::k_wgrad_reduce<<<(unsigned)ceil_div((int64_t)Ho * Hi, 256), 256, 0, stream>>>(partial, s.slices, Ho, Hi, out, ldo,
+                                                                                      partial_cs, colsum);
     HGNN_CHECK_HIP(hipGetLastError());
     return HGNN_OK;
 }

@@ -658,12 +658,51 @@ def set_train_bf16(flag: bool, wgrad_hip: bool = True) -> None:
     _train_bf16_enabled, _wgrad_hip = bool(flag), bool(wgrad_hip)
 
 
-def _wgrad(dz: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
-    """fp32 dz^T rows of bf16 operands"""
+def _wgrad(dz: torch.Tensor, rows: torch.Tensor, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 dz^T rows of bf16 operands (+ optionally dz's column sums = the bias gradient, from the same pass)"""
     if _wgrad_hip:
         from .ops import wgrad_bf16
-        return wgrad_bf16(dz, rows)
+        return wgrad_bf16(dz, rows, colsum=colsum)
+    if colsum is not None:
+        colsum.copy_(dz.float().sum(dim=0))
     return (dz.t() @ rows).float()
+
+
+_bwd_fused = True          # A/B: hand-written fused data gradient (hgnn_mlp_backward_layer_bf16) vs library GEMM + row passes
+
+
+def set_bwd_fused(flag: bool) -> None:
+    global _bwd_fused
+    _bwd_fused = bool(flag)
+
+
+def _bwd_layer_supported(K: int, N: int) -> bool:
+    return bool(_lib.load().hgnn_mlp_backward_layer_supported_bf16(int(K), int(N)))
+
+
+def _bwd_layer(dz, W, z_prev, gamma, beta, act, eps, skip=None, want_a=False):
+    """``hgnn_mlp_backward_layer_bf16``.  W: the Linear's fp32 master weight [K, N] (or a column slice of it).
+    LayerNorm form (z_prev given): returns (dz_prev, a_prev or None, dgamma, dbeta); input form: (dx,)."""
+    M, K = int(dz.shape[0]), int(dz.shape[1])
+    N = int(W.shape[1])
+    dev = dz.device
+    wt = _fragment_order(W.detach().t().to(torch.bfloat16).contiguous())      # W^T [N, K] in A-fragment order
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ln = z_prev is not None
+    a_prev = torch.empty((M, N), dtype=torch.bfloat16, device=dev) if (ln and want_a) else None
+    partials = torch.empty((_lib.MLP_BWD_BLOCKS, 2, N), dtype=torch.float32, device=dev) if ln else None
+    gm = gamma.detach().float().contiguous() if ln else None
+    bt = beta.detach().float().contiguous() if ln else None
+    sk = skip.contiguous() if skip is not None else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().hgnn_mlp_backward_layer_bf16(
+            _lib.ptr(dz.contiguous()), M, K, N, _lib.ptr(wt), _lib.ptr(z_prev), _lib.ptr(gm), _lib.ptr(bt), int(act),
+            float(eps), _lib.ptr(sk), _lib.ptr(out), _lib.ptr(a_prev), _lib.ptr(partials),
+            _lib.current_stream(dev)), "hgnn_mlp_backward_layer_bf16")
+    if not ln:
+        return (out,)
+    sums = partials.sum(dim=0)
+    return out, a_prev, sums[0], sums[1]
 
 
 def _seg_reduce_wide(plan, dz):
@@ -747,44 +786,75 @@ class _FusedMLPTrainBf16(torch.autograd.Function):
         g = grad_out.contiguous().to(bf)
         grads_params = [None] * (4 * n)
         grads_tables = [None] * n_seg
-        da = g
-        for l in range(n - 1, -1, -1):
-            dz, dlw, dlb, dbias = _ln_act_backward(zs[l], da, lnw[l], lnb[l], ctx.acts[l], ctx.eps)
-            pdt = params[4 * l].dtype
-            grads_params[4 * l + 1] = dbias.to(pdt)
-            grads_params[4 * l + 2] = dlw.to(pdt)
-            grads_params[4 * l + 3] = dlb.to(pdt)
-            if l > 0:
-                a_prev = _ln_act_forward(zs[l - 1], lnw[l - 1], lnb[l - 1], ctx.acts[l - 1], ctx.eps)
-                grads_params[4 * l] = _wgrad(dz, a_prev).to(pdt)
+        pdt = [params[4 * l].dtype for l in range(n)]
+        # last layer: its LayerNorm / activation backward has no GEMM in front of it (one HIP row pass)
+        dz, dlw, dlb, dbias = _ln_act_backward(zs[n - 1], g, lnw[n - 1], lnb[n - 1], ctx.acts[n - 1], ctx.eps)
+        grads_params[4 * (n - 1) + 1] = dbias.to(pdt[n - 1])
+        grads_params[4 * (n - 1) + 2] = dlw.to(pdt[n - 1])
+        grads_params[4 * (n - 1) + 3] = dlb.to(pdt[n - 1])
+        for l in range(n - 1, 0, -1):
+            K, N = int(W[l].shape[0]), int(W[l].shape[1])
+            need_bias = grads_params[4 * l + 1] is None
+            colsum = torch.empty(K, dtype=torch.float32, device=dz.device) if need_bias and _wgrad_hip else None
+            if _bwd_fused and _bwd_layer_supported(K, N):
+                # hand-written data gradient fused with the LayerNorm / activation backward of the layer below
+                dz_prev, a_prev, dlw, dlb = _bwd_layer(dz, W[l], zs[l - 1], lnw[l - 1], lnb[l - 1], ctx.acts[l - 1],
+                                                       ctx.eps, want_a=True)
+                grads_params[4 * l] = _wgrad(dz, a_prev, colsum).to(pdt[l])
                 del a_prev
-                da = dz @ W[l].detach().to(bf)                      # data gradient: bf16 library GEMM
+                dbias_prev = None                                         # comes out of layer l-1's weight gradient
             else:
-                # first layer: gathered segments factor through S = segment_reduce(dz, idx) (see _FusedMLPTrain)
-                W0 = W[0].detach().to(bf)
-                dW = torch.empty(tuple(W[0].shape), dtype=torch.float32, device=dz.device)
-                col = 0
-                for s_i in range(n_seg):
-                    idx = indices[s_i]
-                    tab = tables[s_i].contiguous()
-                    w_s = int(tab.shape[1])
-                    W_s = W0[:, col:col + w_s]
-                    if idx is not None:
-                        S = _seg_reduce_wide(get_plan(idx, int(tab.shape[0])), dz)
-                        dW[:, col:col + w_s] = _wgrad(S, tab)
-                        if ctx.needs_input_grad[3 + s_i]:
-                            grads_tables[s_i] = S @ W_s
-                        del S
+                a_prev = _ln_act_forward(zs[l - 1], lnw[l - 1], lnb[l - 1], ctx.acts[l - 1], ctx.eps)
+                grads_params[4 * l] = _wgrad(dz, a_prev, colsum).to(pdt[l])
+                del a_prev
+                da = dz @ W[l].detach().to(bf)                            # data gradient: bf16 library GEMM
+                dz_prev, dlw, dlb, dbias_prev = _ln_act_backward(zs[l - 1], da, lnw[l - 1], lnb[l - 1],
+                                                                 ctx.acts[l - 1], ctx.eps)
+                del da
+            if need_bias:
+                grads_params[4 * l + 1] = (colsum if colsum is not None else dz.float().sum(dim=0)).to(pdt[l])
+            grads_params[4 * (l - 1) + 2] = dlw.to(pdt[l - 1])
+            grads_params[4 * (l - 1) + 3] = dlb.to(pdt[l - 1])
+            if dbias_prev is not None:
+                grads_params[4 * (l - 1) + 1] = dbias_prev.to(pdt[l - 1])
+            dz = dz_prev
+        # first layer: gathered segments factor through S = segment_reduce(dz, idx) (see _FusedMLPTrain)
+        need_bias = grads_params[1] is None
+        W0 = W[0].detach().to(bf)
+        dW = torch.empty(tuple(W[0].shape), dtype=torch.float32, device=dz.device)
+        H0 = int(W[0].shape[0])
+        col = 0
+        for s_i in range(n_seg):
+            idx = indices[s_i]
+            tab = tables[s_i].contiguous()
+            w_s = int(tab.shape[1])
+            W_s = W0[:, col:col + w_s]
+            if idx is not None:
+                S = _seg_reduce_wide(get_plan(idx, int(tab.shape[0])), dz)
+                dW[:, col:col + w_s] = _wgrad(S, tab)
+                if ctx.needs_input_grad[3 + s_i]:
+                    grads_tables[s_i] = S @ W_s
+                del S
+            else:
+                colsum = None
+                if need_bias and _wgrad_hip:
+                    colsum = torch.empty(H0, dtype=torch.float32, device=dz.device)
+                dW[:, col:col + w_s] = _wgrad(dz, tab, colsum)
+                if colsum is not None:
+                    grads_params[1] = colsum.to(pdt[0])
+                    need_bias = False
+                if ctx.needs_input_grad[3 + s_i]:
+                    folded = ctx.skip_seg == s_i          # edges + MLP(..., edges): both gradients in one epilogue
+                    if _bwd_fused and _bwd_layer_supported(H0, w_s):
+                        grads_tables[s_i] = _bwd_layer(dz, W[0][:, col:col + w_s], None, None, None, 0, ctx.eps,
+                                                       skip=g if folded else None)[0]
+                    elif folded:
+                        grads_tables[s_i] = torch.addmm(g, dz, W_s)
                     else:
-                        dW[:, col:col + w_s] = _wgrad(dz, tab)
-                        if ctx.needs_input_grad[3 + s_i]:
-                            if ctx.skip_seg == s_i:
-                                # the skip connection adds this very tensor (edges + MLP(..., edges)): its two
-                                # gradient contributions in ONE GEMM epilogue instead of a separate 3 GB add pass
-                                grads_tables[s_i] = torch.addmm(g, dz, W_s)
-                            else:
-                                grads_tables[s_i] = dz @ W_s
-                    col += w_s
-                grads_params[0] = dW.to(pdt)
+                        grads_tables[s_i] = dz @ W_s
+            col += w_s
+        if need_bias:
+            grads_params[1] = dz.float().sum(dim=0).to(pdt[0])
+        grads_params[0] = dW.to(pdt[0])
         grad_skip = [None if ctx.skip_seg >= 0 else g] if ctx.has_skip else []
         return (None, None, None, *grads_tables, *grad_skip, *grads_params)

@@ -346,10 +346,12 @@ def knn_radius(query: torch.Tensor, points: torch.Tensor, k: int, radius, return
     return (idx, d2) if return_dist2 else idx
 
 
-def wgrad_bf16(dz: torch.Tensor, rows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def wgrad_bf16(dz: torch.Tensor, rows: torch.Tensor, out: Optional[torch.Tensor] = None,
+               colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``dz^T @ rows`` for bf16 ``dz[M, Ho]`` and ``rows[M, Hi]`` (row-major, possibly column slices of wider
     matrices) in fp32: the weight gradient of a Linear layer, by the hand-written split-K bf16-MFMA kernel
-    (``hgnn_wgrad_bf16``; deterministic).  ``out`` (fp32 [Ho, Hi], possibly a column slice) is written in place."""
+    (``hgnn_wgrad_bf16``; deterministic).  ``out`` (fp32 [Ho, Hi], possibly a column slice) is written in place;
+    ``colsum`` (fp32 [Ho], optional) receives ``dz.sum(0)`` -- the Linear's bias gradient -- from the same pass."""
     _require_hip(dz, "dz", allow_bf16=True)
     _require_hip(rows, "rows", allow_bf16=True)
     if dz.dtype != torch.bfloat16 or rows.dtype != torch.bfloat16 or dz.dim() != 2 or rows.dim() != 2 \
@@ -371,7 +373,10 @@ def wgrad_bf16(dz: torch.Tensor, rows: torch.Tensor, out: Optional[torch.Tensor]
     lda = int(dz.stride(0)) if M > 1 else Ho
     ldb = int(rows.stride(0)) if M > 1 else Hi
     with torch.cuda.device(dz.device):
+        if colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != Ho or not colsum.is_contiguous()):
+            raise RuntimeError("wgrad_bf16: colsum must be a contiguous fp32 [Ho] tensor")
         _lib.check(lib.hgnn_wgrad_bf16(_lib.ptr(dz), lda, _lib.ptr(rows), ldb, M, Ho, Hi,
-                                       ctypes.c_void_p(out.data_ptr()), int(out.stride(0)), _lib.ptr(ws), ws.numel(),
-                                       _lib.current_stream(dz.device)), "hgnn_wgrad_bf16")
+                                       ctypes.c_void_p(out.data_ptr()), int(out.stride(0)),
+                                       ctypes.c_void_p(colsum.data_ptr()) if colsum is not None else None,
+                                       _lib.ptr(ws), ws.numel(), _lib.current_stream(dz.device)), "hgnn_wgrad_bf16")
     return out

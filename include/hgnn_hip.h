@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 15
+#define HGNN_ABI_VERSION 16
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -113,6 +113,8 @@ int hgnn_sizeof_mlp_desc(void);
  *                  (L=256: x 128 rows; L=512: x 64 rows, the default there)
  *   "mlp_split_variant" schedule of the feature-split bf16 MLP: -1 (default) per shape, 0 counted
  *                  per-fragment waits, 2 one wait per k-chunk ("burst")
+ *   "mlp_bwd_shape" fused bf16 backward layer, N = 512: 0 (default) 8 waves x 64 rows, 1 = 4 waves with the raw
+ *                  z' tile reloaded per phase (A/B: spills, 6.2 vs 3.2 ms)
  *   "mlp_ablate"   DIAGNOSTIC bits, results are WRONG.  fp32 / bf16 kernels: 1 skip LayerNorm/act,
  *                  2 skip weight DMA, 4 skip barriers (tools/tune_mlp.py); feature-split bf16
  *                  kernel: 1 weights from chunk 0 only, 2 skip LayerNorm/act, 4 load only the first
@@ -355,7 +357,25 @@ int hgnn_ln_act_backward_bf16(const void* z, const void* grad_out, int64_t M, in
                               float* partials /* [HGNN_LN_ACT_BLOCKS][3][W] */, hgnn_stream_t stream);
 int hgnn_wgrad_workspace_bytes(int64_t M, int32_t Ho, int32_t Hi, size_t* bytes);
 int hgnn_wgrad_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int32_t Ho, int32_t Hi,
-                    float* out, int64_t ldo, void* workspace, size_t workspace_bytes, hgnn_stream_t stream);
+                    float* out, int64_t ldo, float* colsum /* [Ho] = sum_m A[m, ho] (the bias gradient), or NULL */,
+                    void* workspace, size_t workspace_bytes, hgnn_stream_t stream);
+
+/* hgnn_mlp_backward_layer_bf16: the hand-written DATA gradient of one Linear of the bf16 training path, fused with
+ * what follows it in the backward:
+ *   z_prev != NULL ("LayerNorm form"):  da = dz[M,K] . W[K,N];  out = dz' = dLayerNorm(act'(LN(z_prev)) * da)  with
+ *       z_prev [M,N] the previous layer's pre-LayerNorm rows (bf16 dumps of the forward), ln_w / ln_b / act / eps that
+ *       layer's LayerNorm + activation; a_prev (optional) receives act(LN(z_prev)) (the rows hgnn_wgrad_bf16 needs
+ *       for W's gradient); partials: float [HGNN_MLP_BWD_BLOCKS][2][N] per-workgroup column sums of dgamma / dbeta
+ *       (the caller adds them; the bias gradient = column sums of dz' comes from hgnn_wgrad_bf16's colsum);
+ *   z_prev == NULL ("input form"):      out = dz . W (+ skip): gradient of a direct input segment of the first
+ *       layer, the skip connection's gradient (skip [M,N] bf16, may be NULL) added in the epilogue.
+ * Wt_frag: W^T (the [N][K] matrix) in the MFMA A-fragment order of hgnn_mlp_forward_bf16_split.
+ * K a multiple of 128, N in {128, 256, 512}; all rows bf16, fp32 accumulation and LayerNorm arithmetic; deterministic. */
+#define HGNN_MLP_BWD_BLOCKS 512
+int hgnn_mlp_backward_layer_supported_bf16(int32_t K, int32_t N);
+int hgnn_mlp_backward_layer_bf16(const void* dz, int64_t M, int32_t K, int32_t N, const void* Wt_frag,
+                                 const void* z_prev, const float* ln_w, const float* ln_b, int32_t act, float eps,
+                                 const void* skip, void* out, void* a_prev, float* partials, hgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

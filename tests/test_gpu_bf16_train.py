@@ -148,3 +148,61 @@ def test_interaction_cell_bf16_training_against_the_fp32_golden_gradients(ckpt):
     assert rel_err(edges.grad.float().cpu().numpy(), z["grad_edges"]) <= BF16_GRAD
     for k, p in cell.named_parameters():
         assert rel_err(p.grad.cpu().numpy(), z["grad." + k]) <= BF16_GRAD, k
+
+
+@pytest.mark.parametrize("M,K,N,act", [(1000, 256, 512, 1), (777, 512, 256, 1), (130, 128, 256, 2), (64, 256, 128, 3),
+                                        (5000, 512, 512, 1), (1, 128, 128, 1)])
+def test_fused_backward_layer_ln_form(M, K, N, act):
+    """hgnn_mlp_backward_layer_bf16, LayerNorm form: dz' = dLN(act'(LN(z')) * (dz W)), a' = act(LN(z')), dgamma,
+    dbeta -- against fp32 autograd on the same bf16-exact inputs"""
+    from hierarchicalgnn_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    dz = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    W = (torch.randn(K, N, device="cuda", generator=g) / K ** 0.5)
+    z = (1.5 * torch.randn(M, N, device="cuda", generator=g) + 0.2).bfloat16()
+    gamma = 1 + 0.2 * torch.randn(N, device="cuda", generator=g)
+    beta = 0.2 * torch.randn(N, device="cuda", generator=g)
+    acts = {1: torch.nn.functional.gelu, 2: torch.tanh, 3: torch.relu}
+    zf = z.float().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a_ref = acts[act](torch.nn.functional.layer_norm(zf, [N], gm, bt, 1e-5))
+    da = dz.float() @ W.bfloat16().float()
+    a_ref.backward(da)
+    dzp, a_prev, dg, db = fused._bwd_layer(dz, W, z, gamma, beta, act, 1e-5, want_a=True)
+    assert dzp.dtype == torch.bfloat16 and dzp.shape == (M, N)
+    assert rel_err(a_prev.float().cpu().numpy(), a_ref.detach().cpu().numpy()) <= 4e-3
+    assert rel_err(dzp.float().cpu().numpy(), zf.grad.cpu().numpy()) <= 5e-3
+    assert rel_err(dg.cpu().numpy(), gm.grad.cpu().numpy()) <= 1e-4          # fp32 throughout
+    assert rel_err(db.cpu().numpy(), bt.grad.cpu().numpy()) <= 1e-4
+    again = fused._bwd_layer(dz, W, z, gamma, beta, act, 1e-5, want_a=True)
+    assert torch.equal(again[0], dzp) and torch.equal(again[2], dg)           # deterministic
+
+
+@pytest.mark.parametrize("M,K,N,with_skip", [(1000, 512, 256, True), (333, 256, 128, False), (4097, 1024, 512, True)])
+def test_fused_backward_layer_input_form(M, K, N, with_skip):
+    """input form: dx = dz W (+ skip) -- the gradient of a direct first-layer segment with the skip connection's
+    gradient folded into the epilogue"""
+    from hierarchicalgnn_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    dz = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    Wfull = torch.randn(K, 3 * N, device="cuda", generator=g) / K ** 0.5
+    W = Wfull[:, N:2 * N]                                                  # a column slice, as for a segment
+    skip = torch.randn(M, N, device="cuda", generator=g).bfloat16() if with_skip else None
+    out = fused._bwd_layer(dz, W, None, None, None, 0, 1e-5, skip=skip)[0]
+    ref = dz.float() @ W.bfloat16().float()
+    if with_skip:
+        ref = ref + skip.float()
+    assert out.dtype == torch.bfloat16
+    assert rel_err(out.float().cpu().numpy(), ref.cpu().numpy()) <= 4e-3
+
+
+def test_wgrad_bf16_column_sums():
+    from hierarchicalgnn_amd.ops import wgrad_bf16
+    g = torch.Generator(device="cuda").manual_seed(8)
+    for M, Ho, Hi in ((5000, 512, 256), (700, 256, 512), (129, 128, 128)):
+        dz = torch.randn(M, Ho, device="cuda", generator=g).bfloat16()
+        rows = torch.randn(M, Hi, device="cuda", generator=g).bfloat16()
+        cs = torch.empty(Ho, device="cuda")
+        out = wgrad_bf16(dz, rows, colsum=cs)
+        assert rel_err(out.cpu().numpy(), (dz.float().t() @ rows.float()).cpu().numpy()) <= 2e-5
+        assert rel_err(cs.cpu().numpy(), dz.float().sum(0).cpu().numpy()) <= 2e-5

