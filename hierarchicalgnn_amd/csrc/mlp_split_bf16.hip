@@ -500,6 +500,9 @@ extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hg
             case 128: return fs::launch<4, 2, 0, 2>(a, stream);
             case 256:
                 if (g_opt_mlp_split_shape == 1) return fs::launch<4, 2, 0, 1, 8, 8>(a, stream);  // A/B only: slower
+                // (measured in round 2 and removed again: 4 waves x 128 rows -- one weight fragment feeds 8 MFMAs, half
+                // the L1 weight traffic per FLOP, 256 accumulators per lane, one wave per SIMD -- spills 219 registers
+                // under hipcc and runs at 4.35 ms vs 2.9 ms)
                 return fs::launch<8, 4, 0, 2>(a, stream);
             case 512:
                 // 8 waves share the 64 rows (2 per SIMD instead of 1): 8.6 vs 9.6 ms at M = 2M
