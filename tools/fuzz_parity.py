@@ -114,4 +114,62 @@ for case in range(n_cases):
             out = mlp.concat_mlp(net, segs16, skip=segs16[2][0]).float()
         note("fused_mlp_bf16_vs_fp32", rel(out, ref), 3e-2, (L, layers, Mm, n_tab))
 
+    # ---------------- round 2: bf16 training kernels (weight gradient, fused backward layer, training gradients)
+    from hierarchicalgnn_amd.ops import wgrad_bf16
+    Mw, Ho, Hi = ri(0, 9000), 8 * ri(1, 80), 8 * ri(1, 80)
+    dzw = torch.randn(Mw, Ho, generator=g).cuda().bfloat16()
+    rows = torch.randn(Mw, Hi, generator=g).cuda().bfloat16()
+    cs = torch.empty(Ho, device="cuda")
+    outw = wgrad_bf16(dzw, rows, colsum=cs)
+    refw = dzw.float().t() @ rows.float()
+    note("wgrad_bf16", rel(outw, refw) if Mw else float(outw.abs().sum()), 3e-5, (Mw, Ho, Hi))
+    note("wgrad_bf16_colsum", rel(cs, dzw.float().sum(0)) if Mw else float(cs.abs().sum()), 3e-5, (Mw, Ho))
+    Kb, Nb, Mb = 128 * ri(1, 6), [128, 256, 512][ri(0, 2)], ri(1, 4000)
+    actb = ri(1, 3)
+    dzb = torch.randn(Mb, Kb, generator=g).cuda().bfloat16()
+    Wb = (torch.randn(Kb, Nb, generator=g) / Kb ** 0.5).cuda()
+    zb = (1.5 * torch.randn(Mb, Nb, generator=g) + 0.2).cuda().bfloat16()
+    gmb = (1 + 0.2 * torch.randn(Nb, generator=g)).cuda()
+    btb = (0.2 * torch.randn(Nb, generator=g)).cuda()
+    zf = zb.float().requires_grad_(True)
+    gmr, btr = gmb.clone().requires_grad_(True), btb.clone().requires_grad_(True)
+    fn = {1: torch.nn.functional.gelu, 2: torch.tanh, 3: torch.relu}[actb]
+    fn(torch.nn.functional.layer_norm(zf, [Nb], gmr, btr, 1e-5)).backward(dzb.float() @ Wb.bfloat16().float())
+    dzp, _, dgb, dbb = fused._bwd_layer(dzb, Wb, zb, gmb, btb, actb, 1e-5, want_a=True)
+    note("bwd_layer_bf16_dz", rel(dzp.float(), zf.grad), 6e-3, (Mb, Kb, Nb, actb))
+    note("bwd_layer_bf16_dgamma", rel(dgb, gmr.grad), 2e-4, (Mb, Kb, Nb, actb))
+    note("bwd_layer_bf16_dbeta", rel(dbb, btr.grad), 2e-4, (Mb, Kb, Nb, actb))
+    skb = torch.randn(Mb, Nb, generator=g).cuda().bfloat16()
+    dxb = fused._bwd_layer(dzb, Wb, None, None, None, 0, 1e-5, skip=skb)[0]
+    note("bwd_layer_bf16_input_form", rel(dxb.float(), dzb.float() @ Wb.bfloat16().float() + skb.float()), 6e-3, (Mb, Kb, Nb))
+    if L >= 128:
+        t3 = tab.bfloat16().clone().requires_grad_(True)
+        d3 = direct.bfloat16().clone().requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        n0 = fused.stats["fused_train_calls"]
+        (mlp.concat_mlp(net, [(t3, i0), (t3, i1), (d3, None)], skip=d3).float() * r).sum().backward()
+        assert fused.stats["fused_train_calls"] == n0 + 1
+        got16 = [t3.grad.float(), d3.grad.float()] + [p.grad.clone() for p in net.parameters()]
+        for k, (a, b) in enumerate(zip(got16, want)):
+            note("fused_mlp_bf16_train_grads_vs_fp32", rel(a, b), 5e-2, (L, layers, Mm, n_tab, k))
+
+    # ---------------- round 2: connected components (union-find) against a sequential union-find on the host
+    from hierarchicalgnn_amd.clustering import connected_components
+    nv, ne = ri(1, 4000), ri(0, 6000)
+    cs_, cd_ = torch.randint(0, nv, (ne,), generator=g), torch.randint(0, nv, (ne,), generator=g)
+    lab = connected_components(cs_.cuda(), cd_.cuda(), nv).cpu().tolist()
+    par = list(range(nv))
+
+    def find(v):
+        while par[v] != v:
+            par[v] = par[par[v]]
+            v = par[v]
+        return v
+
+    for u, v in zip(cs_.tolist(), cd_.tolist()):
+        ru, rv = find(u), find(v)
+        if ru != rv:
+            par[max(ru, rv)] = min(ru, rv)
+    assert lab == [find(v) for v in range(nv)], ("connected_components", nv, ne)
+
 print("cases", n_cases, "seed", seed, "worst relative errors:", {k: f"{v:.2e}" for k, v in worst.items()})
