@@ -420,3 +420,133 @@ def distributed_ec_forward_model(model, shard: EventShard, halo: HaloExchange, p
     return distributed_ec_forward(blk._encode_nodes, blk._encode_edges, list(blk.ignn_cells),
                                   lambda rows: concat_mlp(model.edge_classifier, [(rows, None)]),
                                   shard, halo, pairs, x_owned, group)
+
+
+# --------------------------------------------------------------------------- whole BC-HGNN-GMM model on shards
+def all_owned_lists(x: torch.Tensor, edge_index: torch.Tensor, world: int) -> List[torch.Tensor]:
+    """global hit ids of every rank's owned block, in local-row order (what partition_event gives a rank for
+    itself, for all ranks: deterministic, every rank derives the same lists)"""
+    graph = torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    owner, pos = node_owner(x, graph, world)
+    out = []
+    for r in range(world):
+        own = torch.nonzero(owner == r).squeeze(1)
+        out.append(own[torch.argsort(pos[own])])
+    return out
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """all ranks' row blocks (different lengths) -> one [N_global, F] table in global row order on every rank.
+    Padded all_gather; backward: every rank receives the sum over ranks of the gradient rows of ITS block
+    (the table is consumed by replicated computations whose loss terms are split over the ranks)."""
+
+    @staticmethod
+    def forward(ctx, rows, owned_lists, rank, group):
+        import torch.distributed as dist
+        world = len(owned_lists)
+        block = max(int(o.numel()) for o in owned_lists)
+        pad = rows.new_zeros((block,) + tuple(rows.shape[1:]))
+        pad[:rows.shape[0]] = rows
+        gathered = rows.new_empty((world * block,) + tuple(rows.shape[1:]))
+        dist.all_gather_into_tensor(gathered, pad.contiguous(), group=group)
+        n_global = sum(int(o.numel()) for o in owned_lists)
+        table = rows.new_zeros((n_global,) + tuple(rows.shape[1:]))
+        for r, own in enumerate(owned_lists):
+            table[own.to(rows.device)] = gathered[r * block:r * block + own.numel()]
+        ctx.owned, ctx.rank, ctx.group = owned_lists[rank], rank, group
+        return table
+
+    @staticmethod
+    def backward(ctx, grad_table):
+        import torch.distributed as dist
+        g = grad_table.contiguous().clone()
+        dist.all_reduce(g, group=ctx.group)
+        return g[ctx.owned.to(g.device)], None, None, None
+
+
+def distributed_bc_forward(pieces, shard: EventShard, halo: HaloExchange, x_owned: torch.Tensor,
+                           owned_lists: List[torch.Tensor], directed_global: torch.Tensor, group=None):
+    """BC_HierarchicalGNN_GMM.forward (BipartiteClassification/Models/HGNN_GMM.py:323-346) on one shard of a
+    node-partitioned event (BASELINE config 5).  ``pieces`` holds the model's own callables:
+
+        node_encode(x), edge_encode(x_ext, graph), ignn_cells, emb_head(nodes) -> L2-normalised embeddings,
+        cluster(emb_global, directed_global) -> (clusters[N], n_clusters)        (no gradients),
+        centroids(emb_global, clusters, n_clusters) -> means[S, emb_dim],
+        super_graph(means) -> (graph[2,Q], weights[Q,1]),
+        bipartite(emb_owned, means) -> (graph[2,B_p] LOCAL hit / global supernode ids, logits-free raw weights[B_p,1]),
+        pool(nodes_owned, bg, bw, S) -> partial sums, supernode_encode(pooled), superedge_encode(supernodes, sg),
+        hgnn_cells, head(rows)
+
+    What is replicated and what is sharded: hits, edges and bipartite edges are sharded by the owner of the hit
+    (destination); the 8-wide embeddings are all-gathered once (N x 8 floats: 15 MB at full pileup) and the
+    hierarchy decision -- GMM cut + connected components over the global directed graph, 1.4 ms per 2M edges on
+    one MI355X -- is run REDUNDANTLY by every rank on identical inputs (deterministic kernels => identical
+    clusters everywhere, no label-exchange protocol); centroids, the super graph, supernodes and superedges are
+    replicated; the node->supernode sums (K5, K3) are all-reduced; the bipartite weights' mean-normalisation
+    (gnn_utils.py:213) uses the all-reduced global mean.  BatchNorm statistics must be frozen (eval mode): the
+    training-mode batch statistics of gnn_utils.py:209 would need a synchronised BatchNorm.
+    Returns (bipartite graph [global hit id, supernode id], scores, embeddings of the owned hits)."""
+    dev = x_owned.device
+    graph = shard.local_graph.to(dev)
+    x_ext = halo.extend(x_owned)
+    nodes = pieces["node_encode"](x_owned)
+    edges = pieces["edge_encode"](x_ext, graph)
+    for cell in pieces["ignn_cells"]:
+        nodes, edges = distributed_cell_forward(cell, halo, nodes, edges, graph)
+    emb_owned = pieces["emb_head"](nodes)
+    emb_global = _AllGatherRows.apply(emb_owned, owned_lists, shard.rank, group)
+    with torch.no_grad():
+        clusters, n_clusters = pieces["cluster"](emb_global, directed_global)
+    means = pieces["centroids"](emb_global, clusters, n_clusters)
+    sg, sw = pieces["super_graph"](means)
+    bg, bw_raw = pieces["bipartite"](emb_owned, means)
+    # gnn_utils.py:213 norm=True: divide by the mean over ALL bipartite edges of the event
+    tot = allreduce_supernode_sums(torch.stack([bw_raw.sum(), bw_raw.new_tensor(float(bw_raw.numel()))]), group)
+    bw = bw_raw / (tot[0] / tot[1].clamp(min=1))
+    pooled = allreduce_supernode_sums(pieces["pool"](nodes, bg, bw, means.shape[0]), group)
+    supernodes = torch.cat([means.to(pooled.dtype), pieces["supernode_encode"](pooled)], dim=-1)
+    superedges = pieces["superedge_encode"](supernodes, sg)
+    for cell in pieces["hgnn_cells"]:
+        nodes, edges, supernodes, superedges = distributed_hgnn_cell_forward(
+            cell, halo, nodes, edges, supernodes, superedges, graph, bg, bw, sg, sw, group)
+    rows = torch.cat([_pack(nodes, bg[0]), _pack(supernodes, bg[1])], dim=1)
+    scores = torch.sigmoid(pieces["head"](rows).squeeze(-1))
+    bg_global = torch.stack([shard.owned_global.to(dev)[bg[0]], bg[1]])
+    return bg_global, scores, emb_owned
+
+
+def bc_pieces_from_model(model):
+    """``pieces`` of a ``hierarchicalgnn_amd.models.BC_MessagePassing`` for ``distributed_bc_forward`` (GPU)"""
+    from .mlp import concat_mlp
+    from .ops import gather_scale_scatter, l1_row_scale, scatter_add
+    import torch.nn as nn
+    blk, hb = model.ignn_block, model.hgnn_block
+    if hb.super_graph_construction.training or hb.bipartite_graph_construction.training:
+        raise RuntimeError("distributed_bc_forward needs frozen BatchNorm statistics (model.eval()); the training-mode "
+                           "batch statistics of gnn_utils.py:209 would need a synchronised BatchNorm")
+    hp = model.hparams
+
+    def centroids(emb, clusters, n):
+        lab = torch.where(clusters >= 0, clusters, torch.full_like(clusters, n)).contiguous()
+        sums = scatter_add(emb, lab, dim=0, dim_size=n + 1, validate=False)[:n]
+        cnt = scatter_add(torch.ones(emb.shape[0], 1, device=emb.device), lab, dim=0, dim_size=n + 1,
+                          validate=False)[:n].clamp_(min=1)
+        return nn.functional.normalize(sums / cnt)
+
+    def bipartite(emb_owned, means):
+        gc = hb.bipartite_graph_construction
+        g = gc.build_graph(emb_owned, means, sym=False, k=hp["bipartitegraph_sparsity"])
+        return g, gc.edge_weights(emb_owned, means, g, norm=False)
+
+    return dict(
+        node_encode=blk._encode_nodes, edge_encode=blk._encode_edges, ignn_cells=list(blk.ignn_cells),
+        emb_head=lambda n: nn.functional.normalize(concat_mlp(blk.output_layer, [(n.float(), None)])),
+        cluster=lambda emb, g: hb.clustering(emb, g, return_count=True),
+        centroids=centroids,
+        super_graph=lambda means: hb.super_graph_construction(means, means, sym=True, norm=True,
+                                                              k=hp["supergraph_sparsity"]),
+        bipartite=bipartite,
+        pool=lambda nodes, bg, bw, S: gather_scale_scatter(nodes, bg[0], bg[1], S, bw, row_scale=l1_row_scale(nodes)),
+        supernode_encode=hb._encode_supernodes, superedge_encode=hb._encode_superedges,
+        hgnn_cells=list(hb.hgnn_cells),
+        head=lambda rows: concat_mlp(model.bipartite_output_layer, [(rows, None)]))

@@ -68,3 +68,34 @@ def test_bench_step_shape_on_rccl_world1(rccl_world1):
         torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert h.shape == (shard.n_halo, 64) and out.shape == (shard.n_owned, 64)
+
+
+def test_distributed_bc_forward_on_rccl_world1(rccl_world1):
+    """BASELINE config 5's model (BC-HGNN-GMM on shards) with a real RCCL communicator of world size 1: the
+    all-gathered embeddings, the replicated hierarchy decision, the all-reduced pooling sums and weight mean run
+    as they do per rank at N > 1; scores equal the plain single-GPU model's on the same bipartite edges"""
+    from hierarchicalgnn_amd import partition
+    from hierarchicalgnn_amd.models import BC_MessagePassing
+    from conftest import load_golden
+    z = load_golden("bc_hgnn_L32.npz")
+    hp = {k[3:]: z[k].item() for k in z.files if k.startswith("hp.")}
+    model = BC_MessagePassing(hp)
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}, strict=True)
+    model = model.cuda().eval()
+    x = torch.from_numpy(z["x"])
+    ei = torch.from_numpy(z["edge_index"])
+    with torch.no_grad():
+        bg_ref, s_ref, emb_ref = model(x.cuda(), ei.cuda())
+    shard = partition.partition_event(x, ei, 1, 0)
+    halo = partition.HaloExchange(shard, "cuda", mode="all_to_all")
+    owned = partition.all_owned_lists(x, ei, 1)
+    assert torch.equal(owned[0], shard.owned_global)
+    directed = torch.cat([ei, ei.flip(0)], dim=1).cuda()
+    with torch.no_grad():
+        bg, s, emb = partition.distributed_bc_forward(partition.bc_pieces_from_model(model), shard, halo,
+                                                      x[shard.owned_global].cuda(), owned, directed)
+    key = lambda g: (g[0] * 100000 + g[1]).cpu()
+    o_ref, o = torch.argsort(key(bg_ref)), torch.argsort(key(bg))
+    assert torch.equal(key(bg_ref)[o_ref], key(bg)[o])                   # the same bipartite edges
+    assert torch.allclose(s.cpu()[o], s_ref.cpu()[o_ref], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(emb.cpu(), emb_ref.cpu()[shard.owned_global], rtol=1e-4, atol=1e-5)
