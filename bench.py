@@ -200,6 +200,7 @@ def main():
     plan_ms = sorted(builds)[1]
     side = torch.cuda.Stream(device) if halo is not None else None
 
+    @torch.no_grad()       # inference-style step: no autograd bookkeeping on the host between launches
     def step():
         if halo is not None:
             side.wait_stream(torch.cuda.current_stream())

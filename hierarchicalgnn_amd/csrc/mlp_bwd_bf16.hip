@@ -66,10 +66,20 @@ __device__ __forceinline__ u16x4 pack4(f32x4 v) {
 __device__ __forceinline__ void act_val_grad(float y, int act, float& val, float& grad) {
     switch (act) {
         case HGNN_ACT_GELU: {
-            const float cdf = 0.5f * (1.0f + fast_erf(y * 0.70710678118654752440f));
-            const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * y * y);
+            // Phi(y) = 0.5 (1 + erf(y / sqrt 2)) by Abramowitz-Stegun 7.1.26 (as fast_erf), whose exp(-(y/sqrt 2)^2)
+            // IS exp(-y^2 / 2), the Gaussian of the derivative's phi(y): one exp for both
+            const float ax = __builtin_fabsf(y) * 0.70710678118654752440f;
+            const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+            float p = fmaf(1.061405429f, t, -1.453152027f);
+            p = fmaf(p, t, 1.421413741f);
+            p = fmaf(p, t, -0.284496736f);
+            p = fmaf(p, t, 0.254829592f);
+            p *= t;
+            const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * ax * ax);
+            const float erf_abs = fmaf(-p, e, 1.0f);
+            const float cdf = fmaf(0.5f, __builtin_copysignf(erf_abs, y), 0.5f);
             val = y * cdf;
-            grad = fmaf(y, pdf, cdf);
+            grad = fmaf(y, 0.3989422804014327f * e, cdf);
             return;
         }
         case HGNN_ACT_TANH: {
