@@ -23,7 +23,11 @@ hp = dict(spatial_channels=3, latent=L, hidden=2 * L, emb_dim=8, n_interaction_g
 model = BC_MessagePassing(hp).cuda().eval()
 model.hgnn_block.super_graph_construction.knn_radius.fill_(2.0)
 model.hgnn_block.bipartite_graph_construction.knn_radius.fill_(2.0)
-x, ei = synth.trackml_event()
+# HGNN_EVENT=full_pileup: the BASELINE config 5 event (480k hits / 4M edges -> 8M directed rows) on ONE GPU
+if os.environ.get("HGNN_EVENT") == "full_pileup":
+    x, ei = synth.trackml_event(480_000, 4_000_000)
+else:
+    x, ei = synth.trackml_event()
 x, ei = x.cuda(), ei.cuda()
 S = 10_000
 # stand-in for the (host-side, out-of-scope) GMM + connected-components clustering: phi-z cells
