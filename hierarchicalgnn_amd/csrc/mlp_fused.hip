@@ -346,25 +346,33 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_fused_mlp(const MlpArgs a) {
     // older of the two.  Epilogues run at priority 0, MFMA loops at priority 2.
     __builtin_amdgcn_s_setprio(0);
     dump_pre<NT1>(acc1, a.save_pre[0], e, valid, g);
+    if constexpr (NT2 == 0) {
+        // single-layer launch (fp32 at latent 512: a 1024-wide hidden layer is 256 accumulators per lane, so the
+        // layers of an MLP run as separate launches and the hidden rows make one trip through HBM)
+        if (!(a.ablate & 1)) layernorm_act<NT1, ACT_O>(acc1, a.lnw[0], a.lnb[0], a.act[0], a.eps, g);
+        store_out<NT1>(acc1, a, e, valid, g);
+        return;
+    }
     if (!(a.ablate & 1)) layernorm_act<NT1, ACT_H>(acc1, a.lnw[0], a.lnb[0], a.act[0], a.eps, g);
     __builtin_amdgcn_s_setprio(2);
 
     // ---------------- layer 2 (and 3): activations stay in registers
-    f32x4 acc2[NT2];
-    init_bias<NT2>(acc2, a.b[1], g);
-    dense_from_regs<NT1, NT2, NW>(acc1, acc2, a.W[1], lds, wave, lane, a.ablate);
+    f32x4 acc2[NT2 > 0 ? NT2 : 2];
+    constexpr int N2 = NT2 > 0 ? NT2 : 2;   // (NT2 == 0 returned above; N2 only keeps the dead code well-formed)
+    init_bias<N2>(acc2, a.b[1], g);
+    dense_from_regs<NT1, N2, NW>(acc1, acc2, a.W[1], lds, wave, lane, a.ablate);
     __builtin_amdgcn_s_setprio(0);
-    dump_pre<NT2>(acc2, a.save_pre[1], e, valid, g);
+    dump_pre<N2>(acc2, a.save_pre[1], e, valid, g);
     if (!(a.ablate & 1))
-        layernorm_act<NT2, (NT3 == 0 ? ACT_O : ACT_H), !(PLAIN_LAST && NT3 == 0), (PARTIAL && NT3 == 0)>(
-            acc2, a.lnw[1], a.lnb[1], a.act[1], a.eps, g, NT3 == 0 ? a.n_out_real : NT2 * 16);
+        layernorm_act<N2, (NT3 == 0 ? ACT_O : ACT_H), !(PLAIN_LAST && NT3 == 0), (PARTIAL && NT3 == 0)>(
+            acc2, a.lnw[1], a.lnb[1], a.act[1], a.eps, g, NT3 == 0 ? a.n_out_real : N2 * 16);
     if constexpr (NT3 == 0) {
-        store_out<NT2, PARTIAL>(acc2, a, e, valid, g);
+        store_out<N2, PARTIAL>(acc2, a, e, valid, g);
     } else {
         f32x4 acc3[NT3];
         init_bias<NT3>(acc3, a.b[2], g);
         __builtin_amdgcn_s_setprio(2);
-        dense_from_regs<NT2, NT3, NW>(acc2, acc3, a.W[2], lds, wave, lane, a.ablate);
+        dense_from_regs<N2, NT3, NW>(acc2, acc3, a.W[2], lds, wave, lane, a.ablate);
         __builtin_amdgcn_s_setprio(0);
         dump_pre<NT3>(acc3, a.save_pre[2], e, valid, g);
         if (!(a.ablate & 1))
@@ -417,6 +425,16 @@ static int launch_mlp(const MlpArgs& a, hipStream_t s) {
     return launch_mlp_act<NT1, NT2, NT3, MINW, -1, -1>(a, s);
 }
 
+// one Linear -> LayerNorm -> act (+ skip) layer: the pieces of an fp32 MLP at latent 512
+template <int NT1, int MINW>
+static int launch_single(const MlpArgs& a, hipStream_t s) {
+    switch (a.act[0]) {
+        case HGNN_ACT_GELU: return launch_mlp_act<NT1, 0, 0, MINW, HGNN_ACT_GELU, HGNN_ACT_GELU>(a, s);
+        case HGNN_ACT_TANH: return launch_mlp_act<NT1, 0, 0, MINW, HGNN_ACT_TANH, HGNN_ACT_TANH>(a, s);
+    }
+    return launch_mlp_act<NT1, 0, 0, MINW, -1, -1>(a, s);
+}
+
 // heads: K -> H -> H -> w with a PLAIN last layer of w <= 32 real outputs (padded to 32 rows): the width-1
 // classifiers (IN.py:107-115, HGNN_GMM.py:313-321) and the emb_dim-wide embedding head (HGNN_GMM.py:74-82);
 // LayerNorm + act on the two hidden layers only
@@ -442,7 +460,7 @@ using namespace hgnn;
 
 extern "C" int hgnn_mlp_supported(const hgnn_mlp_desc* d) {
     if (d == nullptr) return 0;
-    if (d->n_seg < 1 || d->n_seg > 3 || (d->n_layers != 2 && d->n_layers != 3)) return 0;
+    if (d->n_seg < 1 || d->n_seg > 3 || d->n_layers < 1 || d->n_layers > 3) return 0;
     int k = 0;
     bool aligned16 = true;
     for (int s = 0; s < d->n_seg; ++s) {
@@ -464,6 +482,12 @@ extern "C" int hgnn_mlp_supported(const hgnn_mlp_desc* d) {
         if (d->pre_table[s] == nullptr || d->pre_index[s] == nullptr) return 0;
     const int h = d->width[1];
     const int o = d->width[n];
+    if (n == 1) {
+        // a single Linear -> LayerNorm -> act (+ skip) layer, 512 or 1024 wide: the building block of the fp32
+        // MLPs at latent 512 (hidden 1024), which do not fit one launch
+        if (d->ln_w[0] == nullptr || d->ln_b[0] == nullptr || d->w_last_rows != 0 || d->save_pre[0] != nullptr) return 0;
+        return (o == 512 || o == 1024) ? 1 : 0;
+    }
     if (n == 3 && d->width[2] != h) return 0;
     if (is_head(d)) {
         // K -> H -> H -> w (w <= 32): LayerNorm on the hidden layers only, plain last layer stored as 32 rows
@@ -561,6 +585,12 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
         }
     }
     const int o = d->width[d->n_layers];
+    if (d->n_layers == 1) {
+        switch (o) {
+            case 512: return launch_single<32, 2>(a, stream);
+            case 1024: return launch_single<64, 1>(a, stream);
+        }
+    }
     if (d->n_layers == 2) {
         switch (o) {
             case 32: return launch_mlp<4, 2, 0, 2>(a, stream);

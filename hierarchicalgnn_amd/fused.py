@@ -107,7 +107,7 @@ def _descriptor(net, segments, skip, dry=False):
     """(descriptor, keep-alive list, M, n_out) for hgnn_mlp_forward_f32, or None.  ``dry``: only decide
     supportability (no projection GEMMs are run; the descriptor must not be launched)."""
     layers = _parse(net)
-    if layers is None or len(layers) not in (2, 3) or not (1 <= len(segments) <= 3):
+    if layers is None or len(layers) not in (1, 2, 3) or not (1 <= len(segments) <= 3):
         return None
     if any(ln is None for _, ln, _ in layers[:-1]):
         return None
@@ -356,11 +356,40 @@ def _descriptor_bf16(net, segments, skip, split=False, dry=False):
     return d, keep, M, n_out
 
 
+def _layer_chain(net):
+    """fp32 MLPs too wide for one launch (latent 512: a 1024-wide hidden layer is 256 accumulators per lane): the
+    [Linear, LayerNorm, act] triples as single-layer Sequentials sharing the parameters, or None"""
+    layers = _parse(net)
+    if layers is None or len(layers) < 2 or any(ln is None for _, ln, _ in layers):
+        return None
+    if any(lin.out_features not in (512, 1024) or lin.in_features % 16 for lin, _, _ in layers[1:]) \
+            or layers[0][0].out_features not in (512, 1024):
+        return None
+    mods = list(net)
+    return [nn.Sequential(*mods[3 * i:3 * i + 3]) for i in range(len(layers))]
+
+
+def _chain_supported(net, segments, skip) -> bool:
+    chain = _layer_chain(net)
+    if chain is None:
+        return False
+    try:
+        first = _descriptor(chain[0], segments, None, dry=True)
+    except RuntimeError:
+        return False
+    if first is None or not bool(_lib.load().hgnn_mlp_supported(ctypes.byref(first[0]))):
+        return False
+    last = _parse(net)[-1][0]
+    return skip is None or (skip.is_cuda and skip.dtype == torch.float32 and tuple(skip.shape) == (first[2], last.out_features))
+
+
 def _is_bf16(segments) -> bool:
     return all(t.dtype == torch.bfloat16 for t, _ in segments)
 
 
-def supported(net, segments, skip) -> bool:
+def supported(net, segments, skip, allow_chain: bool = True) -> bool:
+    """``allow_chain``: accept fp32 MLPs that run as one launch per layer (latent 512); a caller that has a cheaper
+    alternative for them (bf16 tail of the encoders in bf16 mode) passes False"""
     if not _enabled:
         return False
     if _is_bf16(segments):
@@ -387,13 +416,24 @@ def supported(net, segments, skip) -> bool:
         desc = _descriptor(net, segments, skip, dry=True)
     except RuntimeError:
         return False
-    if desc is None:
-        return False
-    return bool(_lib.load().hgnn_mlp_supported(ctypes.byref(desc[0])))
+    if desc is not None and bool(_lib.load().hgnn_mlp_supported(ctypes.byref(desc[0]))):
+        return True
+    return allow_chain and _chain_supported(net, segments, skip)
 
 
 def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
     bf16 = _is_bf16(segments)
+    if not bf16:
+        whole = _descriptor(net, segments, skip, dry=True)
+        if (whole is None or not bool(_lib.load().hgnn_mlp_supported(ctypes.byref(whole[0])))) \
+                and _chain_supported(net, segments, skip):
+            # one launch per layer; the hidden rows make one trip through HBM (fp32 at latent 512)
+            chain = _layer_chain(net)
+            segs, out = segments, None
+            for i, sub in enumerate(chain):
+                out = fused_concat_mlp(sub, segs, skip if i == len(chain) - 1 else None)
+                segs = [(out, None)]
+            return out
     split = bf16 and _wants_split(net, segments)
     desc = _descriptor_bf16(net, segments, skip, split) if bf16 else _descriptor(net, segments, skip)
     if desc is None:

@@ -29,7 +29,8 @@ def concat_mlp(net: nn.Sequential, segments: Sequence[Segment], skip: Optional[t
     first Linear in fp32 (hit coordinates must not be rounded to 8 bits) and run the rest -- the wide
     GEMMs -- in bf16; the result is bf16."""
     from . import fused
-    if fused.supported(net, segments, skip):
+    # bf16 latent mode, encoders at latent 512: the bf16 tail below beats one fp32 launch per layer
+    if fused.supported(net, segments, skip, allow_chain=not bf16_tail):
         return fused.fused_concat_mlp(net, segments, skip)
     if fused.supported_train(net, segments, skip):
         return fused.fused_concat_mlp_train(net, segments, skip)

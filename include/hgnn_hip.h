@@ -248,7 +248,7 @@ typedef struct hgnn_mlp_desc {
     const float* seg_table[3];   /* [rows_i, seg_width[i]]                        */
     const int32_t* seg_index[3]; /* int32[M] row gather, or NULL (row e)          */
     int32_t seg_width[3];
-    int32_t n_layers;            /* 1..3                                          */
+    int32_t n_layers;            /* 1..3 (1: see hgnn_mlp_supported, single layers) */
     const float* W[3];           /* Linear weight [out_i, in_i] row-major (torch) */
     const float* b[3];           /* [out_i]                                       */
     const float* ln_w[3];        /* LayerNorm affine, NULL = no LayerNorm         */
@@ -290,6 +290,9 @@ typedef struct hgnn_mlp_desc {
  *   heads: K -> H -> H -> w, 1 <= w <= 32, LayerNorm + activation on the two hidden layers, plain last
  *       layer (ln_w[2] = NULL, act[2] = NONE) stored zero-padded as 32 rows (w_last_rows = 32),
  *       H in {64, 128, 256, 512}, no skip; out is float[M, w];
+ *   single layers: n_layers = 1, K -> o with o in {512, 1024}, LayerNorm + activation (+ skip): the pieces of an
+ *       fp32 MLP at latent 512 (its 1024-wide hidden layer is 256 accumulators per lane: one launch per layer, the
+ *       hidden rows make one trip through HBM);
  *   narrow encoders: K -> 2P -> 2P -> o with P in {32, 64, 128, 256}, P-16 < o < P, o % 4 == 0, the last
  *       layer's W / b / ln_w / ln_b zero padded to P rows (w_last_rows = P), no skip, no save_pre;
  *       LayerNorm over the o real features; out is float[M, o]. */

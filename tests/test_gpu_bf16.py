@@ -224,7 +224,8 @@ def test_latent512_bf16_mode_matches_its_fp32_model():
         ref = ref_model(x, ei)
         n1 = fused.stats["fused_calls"]
         out = model(x, ei)
-    assert fused.stats["fused_calls"] - n1 >= 4 and n1 == n0      # 2 cells x (node + edge) fused in bf16; none in fp32
+    assert fused.stats["fused_calls"] - n1 >= 4                   # 2 cells x (node + edge) fused in bf16
+    assert n1 - n0 >= 2 * (2 + 3)                                   # fp32 at latent 512: one fused launch per layer (round 2)
     assert out.dtype == torch.float32 and out.shape == ref.shape
     d = (out - ref).abs()
     assert float(d.mean()) <= 0.01 and float(d.max()) <= 0.1, (float(d.mean()), float(d.max()))

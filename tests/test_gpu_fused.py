@@ -438,3 +438,32 @@ def test_fused_train_small_k_encoders(L, kind):
     assert rel_err(gx.cpu().numpy(), gx_ref.cpu().numpy()) <= TOL
     for (name, _), a, b in zip(net.named_parameters(), gp, gp_ref):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL, name
+
+
+@pytest.mark.parametrize("layers,nseg,M", [(2, 3, 700), (3, 2, 333), (3, 3, 129)])
+def test_fused_fp32_latent512_layer_chain(layers, nseg, M):
+    """fp32 at latent 512 (hidden 1024 = 256 accumulators per lane: no single-launch kernel): one fused launch per
+    [Linear, LayerNorm, act] layer, gathers / concat / pre-projection in the first, skip in the last"""
+    from hierarchicalgnn_amd import fused
+    from oracle import hgnn_oracle as O
+    L = 512
+    g = torch.Generator().manual_seed(layers * 10 + nseg)
+    out_act = "Tanh" if layers == 2 else "GELU"
+    net = _mk(nseg * L, L, layers, out_act, seed=layers)
+    n_tab = 61
+    table = torch.randn(n_tab, L, generator=g)
+    idx0 = torch.randint(0, n_tab, (M,), generator=g)
+    idx1 = torch.randint(0, n_tab, (M,), generator=g)
+    direct = torch.randn(M, L, generator=g)
+    segs_cpu = [(table, idx0), (table, idx1), (direct, None)][3 - nseg:]
+    x = torch.cat([t if i is None else t[i] for t, i in segs_cpu], dim=1)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = O.mlp_apply(sd, "", x, layers, "GELU", out_act, True) + direct
+    net = net.cuda()
+    segs = [(t.cuda(), None if i is None else i.cuda()) for t, i in segs_cpu]
+    with torch.no_grad():
+        assert fused.supported(net, segs, segs[-1][0])
+        n0 = fused.stats["fused_calls"]
+        out = fused.fused_concat_mlp(net, segs, segs[-1][0])
+        assert fused.stats["fused_calls"] == n0 + layers
+    assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
