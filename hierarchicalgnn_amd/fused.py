@@ -358,15 +358,20 @@ def _descriptor_bf16(net, segments, skip, split=False, dry=False):
 
 def _layer_chain(net):
     """fp32 MLPs too wide for one launch (latent 512: a 1024-wide hidden layer is 256 accumulators per lane): the
-    [Linear, LayerNorm, act] triples as single-layer Sequentials sharing the parameters, or None"""
+    [Linear, LayerNorm, act] triples as single-layer Sequentials sharing the parameters (a plain last Linear -- the
+    width-1 heads -- stays a trailing ``nn.Linear``: an M x 1024 x 1 product), or None"""
     layers = _parse(net)
-    if layers is None or len(layers) < 2 or any(ln is None for _, ln, _ in layers):
+    if layers is None or len(layers) < 2 or any(ln is None for _, ln, _ in layers[:-1]):
         return None
-    if any(lin.out_features not in (512, 1024) or lin.in_features % 16 for lin, _, _ in layers[1:]) \
-            or layers[0][0].out_features not in (512, 1024):
+    fused_layers = layers if layers[-1][1] is not None else layers[:-1]
+    if any(lin.out_features not in (512, 1024) or lin.in_features % 16 for lin, _, _ in fused_layers[1:]) \
+            or fused_layers[0][0].out_features not in (512, 1024):
         return None
     mods = list(net)
-    return [nn.Sequential(*mods[3 * i:3 * i + 3]) for i in range(len(layers))]
+    chain = [nn.Sequential(*mods[3 * i:3 * i + 3]) for i in range(len(fused_layers))]
+    if len(fused_layers) < len(layers):
+        chain.append(layers[-1][0])                      # the plain nn.Linear itself
+    return chain
 
 
 def _chain_supported(net, segments, skip) -> bool:
@@ -380,6 +385,8 @@ def _chain_supported(net, segments, skip) -> bool:
     if first is None or not bool(_lib.load().hgnn_mlp_supported(ctypes.byref(first[0]))):
         return False
     last = _parse(net)[-1][0]
+    if isinstance(chain[-1], nn.Linear) and skip is not None:
+        return False                                      # heads have no skip connection
     return skip is None or (skip.is_cuda and skip.dtype == torch.float32 and tuple(skip.shape) == (first[2], last.out_features))
 
 
@@ -431,8 +438,11 @@ def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
             chain = _layer_chain(net)
             segs, out = segments, None
             for i, sub in enumerate(chain):
-                out = fused_concat_mlp(sub, segs, skip if i == len(chain) - 1 else None)
-                segs = [(out, None)]
+                if isinstance(sub, nn.Linear):
+                    out = torch.nn.functional.linear(out, sub.weight, sub.bias)
+                else:
+                    out = fused_concat_mlp(sub, segs, skip if i == len(chain) - 1 else None)
+                    segs = [(out, None)]
             return out
     split = bf16 and _wants_split(net, segments)
     desc = _descriptor_bf16(net, segments, skip, split) if bf16 else _descriptor(net, segments, skip)

@@ -467,3 +467,28 @@ def test_fused_fp32_latent512_layer_chain(layers, nseg, M):
         out = fused.fused_concat_mlp(net, segs, segs[-1][0])
         assert fused.stats["fused_calls"] == n0 + layers
     assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
+
+
+def test_fused_fp32_latent512_head_chain():
+    """the width-1 classifier head at latent 512 (2L -> 1024 -> 1024 -> 1): the two LayerNorm layers as fused
+    single-layer launches, the plain last Linear as a trailing matrix-vector product"""
+    from hierarchicalgnn_amd import fused, make_mlp
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(99)
+    M, L = 600, 512
+    torch.manual_seed(3)
+    net = make_mlp(2 * L, 2 * L, 1, 3, layer_norm=True, output_activation=None, hidden_activation="GELU")
+    a = torch.randn(M, L, generator=g)
+    tab = torch.randn(40, L, generator=g)
+    idx = torch.randint(0, 40, (M,), generator=g)
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    ref = O.mlp_apply(sd, "", torch.cat([a, tab[idx]], 1), 3, "GELU", None, True)
+    net = net.cuda()
+    segs = [(a.cuda(), None), (tab.cuda(), idx.cuda())]
+    with torch.no_grad():
+        assert fused.supported(net, segs, None)
+        n0 = fused.stats["fused_calls"]
+        out = fused.fused_concat_mlp(net, segs, None)
+        assert fused.stats["fused_calls"] == n0 + 2
+    assert out.shape == (M, 1)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
