@@ -336,6 +336,13 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
         }
     }
     dump_pre<NT1, NW, NJ>(acc1, a.save_pre[0], a.M, e0, wave, ei, g);
+    if constexpr (NT2 == 0) {
+        // single-layer launch (heads / encoder tails at latent 512, whose 1024-wide layers chain as separate launches)
+        layernorm_act<NT1, ACT_O, NW, NJ>(acc1, a.lnw[0] + wave * NT1 * 16 + 4 * g, a.lnb[0] + wave * NT1 * 16 + 4 * g,
+                                          a.act[0], a.eps, red, wave, ei, g, a.ablate);
+        store_out<NT1, NW, NJ>(acc1, a, e0, wave, ei, g);
+        return;
+    }
     layernorm_act<NT1, ACT_H, NW, NJ>(acc1, a.lnw[0] + wave * NT1 * 16 + 4 * g, a.lnb[0] + wave * NT1 * 16 + 4 * g, a.act[0],
                               a.eps, red, wave, ei, g, a.ablate);
     // (the barrier inside layernorm_act also means: every wave is done reading the panels)
@@ -343,24 +350,25 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
     __syncthreads();
 
     // ---------------- layer 2: B = hidden rows
-    f32x4 acc2[NT2][NJ];
-    init_bias<NT2, NJ>(acc2, a.b[1] + wave * NT2 * 16 + 4 * g);
+    constexpr int N2 = NT2 > 0 ? NT2 : 2;   // (NT2 == 0 returned above; N2 only keeps the dead code well-formed)
+    f32x4 acc2[N2][NJ];
+    init_bias<N2, NJ>(acc2, a.b[1] + wave * N2 * 16 + 4 * g);
     {
-        const u16x8* wp = (const u16x8*)a.W[1] + (size_t)(wave * NT2) * 64 + lane;
-        u16x8 w[Ring<NT2>::R];
-        ring_fill<NT2, NW>(w, wp, NC2);
-        gemm_lds<NT2, HRS, VAR, NW, NJ>(acc2, w, wp, 0, NC2, smem + ei * HRS + ((g ^ (SWZ ? (ei & 3) : 0)) << 4), SWZ ? (ei >> 2) : 0, NC2, a.ablate);
+        const u16x8* wp = (const u16x8*)a.W[1] + (size_t)(wave * N2) * 64 + lane;
+        u16x8 w[Ring<N2>::R];
+        ring_fill<N2, NW>(w, wp, NC2);
+        gemm_lds<N2, HRS, VAR, NW, NJ>(acc2, w, wp, 0, NC2, smem + ei * HRS + ((g ^ (SWZ ? (ei & 3) : 0)) << 4), SWZ ? (ei >> 2) : 0, NC2, a.ablate);
     }
-    dump_pre<NT2, NW, NJ>(acc2, a.save_pre[1], a.M, e0, wave, ei, g);
+    dump_pre<N2, NW, NJ>(acc2, a.save_pre[1], a.M, e0, wave, ei, g);
     if constexpr (NT3 == 0) {
-        layernorm_act<NT2, ACT_O, NW, NJ>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
+        layernorm_act<N2, ACT_O, NW, NJ>(acc2, a.lnw[1] + wave * N2 * 16 + 4 * g, a.lnb[1] + wave * N2 * 16 + 4 * g,
                                   a.act[1], a.eps, red, wave, ei, g, a.ablate);
-        store_out<NT2, NW, NJ>(acc2, a, e0, wave, ei, g);
+        store_out<N2, NW, NJ>(acc2, a, e0, wave, ei, g);
     } else {
-        layernorm_act<NT2, ACT_H, NW, NJ>(acc2, a.lnw[1] + wave * NT2 * 16 + 4 * g, a.lnb[1] + wave * NT2 * 16 + 4 * g,
+        layernorm_act<N2, ACT_H, NW, NJ>(acc2, a.lnw[1] + wave * N2 * 16 + 4 * g, a.lnb[1] + wave * N2 * 16 + 4 * g,
                                   a.act[1], a.eps, red, wave, ei, g, a.ablate);
         // in place: the barrier inside layernorm_act came after every wave's layer-2 reads
-        write_hidden<NT2, HRS, NJ, SWZ>(acc2, smem + ei * HRS, 2 * wave * NT2, ei, g);
+        write_hidden<N2, HRS, NJ, SWZ>(acc2, smem + ei * HRS, 2 * wave * N2, ei, g);
         __syncthreads();
         f32x4 acc3[NT3][NJ];
         init_bias<NT3, NJ>(acc3, a.b[2] + wave * NT3 * 16 + 4 * g);
@@ -415,6 +423,23 @@ static int launch(const Args& a, hipStream_t s) {
     return launch_act<NT1, NT2, NT3, MINB, -1, -1, 0, NW, NJ>(a, s);
 }
 
+// one Linear -> LayerNorm -> act (+ skip) layer (n_layers = 1): N = NW * NT * 16 in {512, 1024}
+template <int NT, int MINB, int NW>
+static int launch_single(const Args& a, hipStream_t s) {
+    constexpr int AUTO = (NT == 8 && NW == 4 && MINB == 2) ? 2 : 0;
+    const int var = g_opt_mlp_split_variant < 0 ? AUTO : g_opt_mlp_split_variant;
+    const int act = a.act[0];
+#define HGNN_SINGLE(V)                                                                                          \
+    do {                                                                                                        \
+        if (act == HGNN_ACT_GELU) return launch_act<NT, 0, 0, MINB, HGNN_ACT_GELU, HGNN_ACT_GELU, V, NW, 4>(a, s); \
+        if (act == HGNN_ACT_TANH) return launch_act<NT, 0, 0, MINB, HGNN_ACT_TANH, HGNN_ACT_TANH, V, NW, 4>(a, s); \
+        return launch_act<NT, 0, 0, MINB, -1, -1, V, NW, 4>(a, s);                                               \
+    } while (0)
+    if (var == 2) HGNN_SINGLE(2);
+    HGNN_SINGLE(0);
+#undef HGNN_SINGLE
+}
+
 }  // namespace fs
 }  // namespace hgnn
 
@@ -422,7 +447,7 @@ using namespace hgnn;
 
 extern "C" int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d) {
     if (d == nullptr) return 0;
-    if (d->n_seg < 1 || d->n_seg > 3 || (d->n_layers != 2 && d->n_layers != 3)) return 0;
+    if (d->n_seg < 1 || d->n_seg > 3 || d->n_layers < 1 || d->n_layers > 3) return 0;
     int k = 0;
     for (int s = 0; s < d->n_seg; ++s) {
         if (d->seg_width[s] <= 0 || d->seg_width[s] % 128 != 0) return 0;
@@ -438,6 +463,7 @@ extern "C" int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d) {
     if (d->M < 0 || d->M > 0x7fffffffLL) return 0;
     const int h = d->width[1];
     const int o = d->width[n];
+    if (n == 1) return (o == 512 || o == 1024) && d->n_pre == 0 ? 1 : 0;   // single layers (latent-512 chains)
     if (n == 3 && d->width[2] != h) return 0;
     if (h != 2 * o) return 0;
     return (o == 128 || o == 256 || o == 512) ? 1 : 0;
@@ -495,6 +521,10 @@ extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hg
     HGNN_REQUIRE((uintptr_t)out % 8 == 0 && (uintptr_t)a.skip % 8 == 0,
                  "hgnn_mlp_forward_bf16_split: out/skip must be 8-byte aligned");
     const int o = d->width[d->n_layers];
+    if (d->n_layers == 1) {
+        if (o == 512) return fs::launch_single<8, 2, 4>(a, stream);
+        return fs::launch_single<8, 1, 8>(a, stream);
+    }
     if (d->n_layers == 2) {
         switch (o) {
             case 128: return fs::launch<4, 2, 0, 2>(a, stream);

@@ -252,12 +252,14 @@ def set_bf16_split(flag: bool) -> None:
 
 def _wants_split(net, segments) -> bool:
     layers = _parse(net)
-    if not _bf16_split or layers is None or len(layers) not in (2, 3):
+    if not _bf16_split or layers is None or len(layers) not in (1, 2, 3):
         return False
     if any(int(t.shape[1]) % 128 for t, _ in segments):
         return False
     widths = [lin.out_features for lin, _, _ in layers]
     o = widths[-1]
+    if len(layers) == 1:
+        return layers[0][1] is not None and o in (512, 1024)      # single layers of the latent-512 chains
     return o in (128, 256, 512) and all(w == 2 * o for w in widths[:-1])
 
 
@@ -266,7 +268,7 @@ def _descriptor_bf16(net, segments, skip, split=False, dry=False):
     or, with ``split``, for hgnn_mlp_forward_bf16_split (weights in A-fragment order; gathered segments
     of small tables pre-projected as in the fp32 path, P_s rounded once to bf16)"""
     layers = _parse(net)
-    if layers is None or len(layers) not in (2, 3) or not (1 <= len(segments) <= 3):
+    if layers is None or len(layers) not in (1, 2, 3) or not (1 <= len(segments) <= 3):
         return None
     if any(ln is None for _, ln, _ in layers):
         return None
@@ -378,16 +380,25 @@ def _chain_supported(net, segments, skip) -> bool:
     chain = _layer_chain(net)
     if chain is None:
         return False
+    bf16 = _is_bf16(segments)
     try:
-        first = _descriptor(chain[0], segments, None, dry=True)
+        if bf16:
+            if not _wants_split(chain[0], segments):
+                return False
+            first = _descriptor_bf16(chain[0], segments, None, split=True, dry=True)
+            ok = first is not None and bool(_lib.load().hgnn_mlp_supported_bf16_split(ctypes.byref(first[0])))
+        else:
+            first = _descriptor(chain[0], segments, None, dry=True)
+            ok = first is not None and bool(_lib.load().hgnn_mlp_supported(ctypes.byref(first[0])))
     except RuntimeError:
         return False
-    if first is None or not bool(_lib.load().hgnn_mlp_supported(ctypes.byref(first[0]))):
+    if not ok:
         return False
     last = _parse(net)[-1][0]
     if isinstance(chain[-1], nn.Linear) and skip is not None:
         return False                                      # heads have no skip connection
-    return skip is None or (skip.is_cuda and skip.dtype == torch.float32 and tuple(skip.shape) == (first[2], last.out_features))
+    dt = torch.bfloat16 if bf16 else torch.float32
+    return skip is None or (skip.is_cuda and skip.dtype == dt and tuple(skip.shape) == (first[2], last.out_features))
 
 
 def _is_bf16(segments) -> bool:
@@ -409,12 +420,13 @@ def supported(net, segments, skip, allow_chain: bool = True) -> bool:
             desc = _descriptor_bf16(net, segments, skip, split, dry=True)
         except RuntimeError:
             return False
-        if desc is None:
-            return False
         lib = _lib.load()
-        if split:
-            return bool(lib.hgnn_mlp_supported_bf16_split(ctypes.byref(desc[0])))
-        return bool(lib.hgnn_mlp_supported_bf16(ctypes.byref(desc[0])))
+        if desc is not None:
+            if split and bool(lib.hgnn_mlp_supported_bf16_split(ctypes.byref(desc[0]))):
+                return True
+            if not split and bool(lib.hgnn_mlp_supported_bf16(ctypes.byref(desc[0]))):
+                return True
+        return allow_chain and _chain_supported(net, segments, skip)
     if torch.is_grad_enabled():
         tensors = [t for t, _ in segments] + ([skip] if skip is not None else []) + list(net.parameters())
         if any(t.requires_grad for t in tensors):
@@ -430,16 +442,22 @@ def supported(net, segments, skip, allow_chain: bool = True) -> bool:
 
 def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
     bf16 = _is_bf16(segments)
-    if not bf16:
-        whole = _descriptor(net, segments, skip, dry=True)
-        if (whole is None or not bool(_lib.load().hgnn_mlp_supported(ctypes.byref(whole[0])))) \
-                and _chain_supported(net, segments, skip):
+    if len(_parse(net) or []) > 1:
+        if bf16:
+            sp = _wants_split(net, segments)
+            whole = _descriptor_bf16(net, segments, skip, sp, dry=True)
+            whole_ok = whole is not None and bool((_lib.load().hgnn_mlp_supported_bf16_split if sp else
+                                                   _lib.load().hgnn_mlp_supported_bf16)(ctypes.byref(whole[0])))
+        else:
+            whole = _descriptor(net, segments, skip, dry=True)
+            whole_ok = whole is not None and bool(_lib.load().hgnn_mlp_supported(ctypes.byref(whole[0])))
+        if not whole_ok and _chain_supported(net, segments, skip):
             # one launch per layer; the hidden rows make one trip through HBM (fp32 at latent 512)
             chain = _layer_chain(net)
             segs, out = segments, None
             for i, sub in enumerate(chain):
                 if isinstance(sub, nn.Linear):
-                    out = torch.nn.functional.linear(out, sub.weight, sub.bias)
+                    out = torch.nn.functional.linear(out, sub.weight.to(out.dtype), sub.bias.to(out.dtype))
                 else:
                     out = fused_concat_mlp(sub, segs, skip if i == len(chain) - 1 else None)
                     segs = [(out, None)]

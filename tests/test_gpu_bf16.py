@@ -229,3 +229,67 @@ def test_latent512_bf16_mode_matches_its_fp32_model():
     assert out.dtype == torch.float32 and out.shape == ref.shape
     d = (out - ref).abs()
     assert float(d.mean()) <= 0.01 and float(d.max()) <= 0.1, (float(d.mean()), float(d.max()))
+
+
+@pytest.mark.parametrize("kind,L", [("head", 512), ("head", 256), ("mlp3", 512)])
+def test_bf16_single_layer_chains(kind, L):
+    """bf16 MLPs that do not fit one launch (heads with a plain last layer; 1024-wide layers at latent 512): one
+    feature-split bf16-MFMA launch per [Linear, LayerNorm, act] layer (hgnn_mlp_forward_bf16_split, n_layers = 1)"""
+    from hierarchicalgnn_amd import fused, make_mlp
+    from oracle import hgnn_oracle as O
+    g = torch.Generator().manual_seed(L + len(kind))
+    M = 900
+    torch.manual_seed(L)
+    if kind == "head":
+        net = make_mlp(2 * L, 2 * L, 1, 3, layer_norm=True, output_activation=None, hidden_activation="GELU")
+        a = torch.randn(M, L, generator=g).bfloat16()
+        tab = torch.randn(70, L, generator=g).bfloat16()
+        idx = torch.randint(0, 70, (M,), generator=g)
+        x = torch.cat([a.float(), tab.float()[idx]], 1)
+        segs = [(a.cuda(), None), (tab.cuda(), idx.cuda())]
+        ref = O.mlp_apply({k: v.detach() for k, v in net.state_dict().items()}, "", x, 3, "GELU", None, True)
+        n_launch, skip = 2, None
+    else:
+        net = make_mlp(L, 2 * L, 2 * L, 3, layer_norm=True, output_activation="GELU", hidden_activation="GELU")
+        a = torch.randn(M, L, generator=g).bfloat16()
+        segs = [(a.cuda(), None)]
+        ref = O.mlp_apply({k: v.detach() for k, v in net.state_dict().items()}, "", a.float(), 3, "GELU", "GELU", True)
+        n_launch, skip = 3, None
+    net = net.cuda()
+    with torch.no_grad():
+        assert fused.supported(net, segs, skip)
+        n0 = fused.stats["fused_calls"]
+        out = fused.fused_concat_mlp(net, segs, skip)
+        assert fused.stats["fused_calls"] == n0 + n_launch
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    assert rel_err(out.float().cpu().numpy(), ref.numpy()) <= 3e-2          # three bf16 layers deep
+
+
+@pytest.mark.parametrize("kind", ["node_enc", "edge_enc"])
+def test_bf16_mode_encoders_at_latent512_hybrid_chain(kind):
+    """config 4's encoders (IN.py:84-85 at latent 512, bf16 latent mode): first Linear as one fp32 fused layer (hit
+    coordinates are not rounded), the wide tail on the bf16 feature-split kernel -- no library GEMM"""
+    from hierarchicalgnn_amd import fused, make_mlp, mlp
+    from oracle import hgnn_oracle as O
+    L = 512
+    g = torch.Generator().manual_seed(12)
+    N, M = 300, 2000
+    x = torch.rand(N, 3, generator=g) * 2 - 1
+    i0 = torch.randint(0, N, (M,), generator=g)
+    i1 = torch.randint(0, N, (M,), generator=g)
+    torch.manual_seed(4)
+    if kind == "edge_enc":
+        net = make_mlp(6, 2 * L, L, 2, layer_norm=True, output_activation="GELU", hidden_activation="GELU")
+        segs_cpu, layers, xin, launches = [(x, i0), (x, i1)], 2, torch.cat([x[i0], x[i1]], 1), 2
+    else:
+        net = make_mlp(3, 2 * L, L, 3, layer_norm=True, output_activation="GELU", hidden_activation="GELU")
+        segs_cpu, layers, xin, launches = [(x, None)], 3, x, 2          # fp32 layer + one 2-layer bf16 launch
+    ref = O.mlp_apply({k: v.detach() for k, v in net.state_dict().items()}, "", xin, layers, "GELU", "GELU", True)
+    net = net.cuda()
+    segs = [(t.cuda(), None if i is None else i.cuda()) for t, i in segs_cpu]
+    with torch.no_grad():
+        n0 = fused.stats["fused_calls"]
+        out = mlp.concat_mlp(net, segs, bf16_tail=True)
+        assert fused.stats["fused_calls"] - n0 == launches
+    assert out.dtype == torch.bfloat16
+    assert rel_err(out.float().cpu().numpy(), ref.numpy()) <= 2e-2
