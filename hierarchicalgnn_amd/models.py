@@ -30,12 +30,10 @@ def _bf16_features(hparams) -> bool:
 
 
 def _head_input(t, hparams):
-    """score heads in bf16 latent mode: up to latent 256 the rows are widened and the fused fp32 head kernel runs
-    (no library MLP in an inference forward; measured A/B against a bf16 library head under autocast: latent 128
-    21.6 vs 23.8 ms, latent 256 61.4 vs 58.6 ms per EC-IN forward -- the hand-written kernel is kept, the 4.5 % at
-    latent 256 noted); beyond latent 256 there is no single-launch fp32 head and the rows stay bf16 (library GEMMs
-    under autocast)"""
-    if t.dtype == torch.float32 or int(hparams["latent"]) > 256:
+    """score heads in bf16 latent mode: from latent 256 on (hidden >= 512) the head runs as a chain of single-layer
+    launches of the bf16 feature-split kernel on the bf16 rows; below that (no 256-wide single-layer instantiation)
+    the rows are widened and the fused fp32 head kernel runs.  Either way no library MLP in an inference forward."""
+    if t.dtype == torch.float32 or int(hparams["latent"]) >= 256:
         return t
     if torch.is_grad_enabled() and t.requires_grad:
         # training in bf16 mode: there is no differentiable fused head, so the head's wide GEMMs (1 TFLOP at
