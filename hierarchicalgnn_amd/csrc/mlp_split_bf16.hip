@@ -423,7 +423,7 @@ static int launch(const Args& a, hipStream_t s) {
     return launch_act<NT1, NT2, NT3, MINB, -1, -1, 0, NW, NJ>(a, s);
 }
 
-// one Linear -> LayerNorm -> act (+ skip) layer (n_layers = 1): N = NW * NT * 16 in {512, 1024}
+// one Linear -> LayerNorm -> act (+ skip) layer (n_layers = 1): N = NW * NT * 16 in {256, 512, 1024}
 template <int NT, int MINB, int NW>
 static int launch_single(const Args& a, hipStream_t s) {
     constexpr int AUTO = (NT == 8 && NW == 4 && MINB == 2) ? 2 : 0;
@@ -463,7 +463,7 @@ extern "C" int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d) {
     if (d->M < 0 || d->M > 0x7fffffffLL) return 0;
     const int h = d->width[1];
     const int o = d->width[n];
-    if (n == 1) return (o == 512 || o == 1024) && d->n_pre == 0 ? 1 : 0;   // single layers (latent-512 chains)
+    if (n == 1) return (o == 256 || o == 512 || o == 1024) && d->n_pre == 0 ? 1 : 0;   // single layers (chains)
     if (n == 3 && d->width[2] != h) return 0;
     if (h != 2 * o) return 0;
     return (o == 128 || o == 256 || o == 512) ? 1 : 0;
@@ -522,6 +522,7 @@ extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hg
                  "hgnn_mlp_forward_bf16_split: out/skip must be 8-byte aligned");
     const int o = d->width[d->n_layers];
     if (d->n_layers == 1) {
+        if (o == 256) return fs::launch_single<4, 2, 4>(a, stream);
         if (o == 512) return fs::launch_single<8, 2, 4>(a, stream);
         return fs::launch_single<8, 1, 8>(a, stream);
     }

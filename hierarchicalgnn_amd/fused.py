@@ -259,7 +259,7 @@ def _wants_split(net, segments) -> bool:
     widths = [lin.out_features for lin, _, _ in layers]
     o = widths[-1]
     if len(layers) == 1:
-        return layers[0][1] is not None and o in (512, 1024)      # single layers of the latent-512 chains
+        return layers[0][1] is not None and o in (256, 512, 1024)  # single layers (chains)
     return o in (128, 256, 512) and all(w == 2 * o for w in widths[:-1])
 
 

@@ -319,8 +319,8 @@ int hgnn_mlp_forward_bf16(const hgnn_mlp_desc* d, void* out, hgnn_stream_t strea
  *   element index = ((c * (F/16) + T) * 64 + lane) * 8 + i  holds  W[16T + lane%16][32c + 8(lane/16) + i]
  * (F = out features, c = 32-wide k-chunk, T = 16-feature tile, lane = 0..63, i = 0..7).
  * Supported: K -> 2L (-> 2L) -> L, LayerNorm on every layer, every segment a multiple of 128 wide; and single layers
- * (n_layers = 1) K -> o, o in {512, 1024}, LayerNorm + activation (+ skip): the pieces from which the heads and the
- * encoder tails of latent 512 are chained.
+ * (n_layers = 1) K -> o, o in {256, 512, 1024}, LayerNorm + activation (+ skip): the pieces from which the heads and
+ * the encoder tails (bf16 latent mode) are chained.
  * save_pre[l] (optional) receives layer l's pre-LayerNorm rows as BF16 [M, width[l+1]] (8-byte aligned): the
  * forward of the bf16 training path. */
 int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d);
