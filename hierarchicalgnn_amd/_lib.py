@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("HGNN_LIB") or os.path.join(_HERE, "csrc", "libhgnn_hi
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 16
+ABI_VERSION = 17
 MLP_BWD_BLOCKS = 512   # HGNN_MLP_BWD_BLOCKS
 GMM_STATE, GMM_BLOCKS = 16, 1024   # HGNN_GMM_STATE, HGNN_GMM_BLOCKS
 LN_ACT_BLOCKS = 1024   # HGNN_LN_ACT_BLOCKS

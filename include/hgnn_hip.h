@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 16
+#define HGNN_ABI_VERSION 17
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
