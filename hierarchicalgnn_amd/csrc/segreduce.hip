@@ -29,6 +29,7 @@ extern int g_opt_mlp_f32_waves;
 extern int g_opt_mlp_split_shape;
 extern int g_opt_mlp_bf16_shape;
 extern int g_opt_bwd_shape;
+extern int g_opt_mlp_rows128;
 
 static int g_opt_nt_loads = 1;   // non-temporal loads for once-read source rows
 static int g_opt_nt_stores = 0;  // non-temporal stores for gather output
@@ -600,6 +601,7 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     else if (!strcmp(name, "mlp_split_shape")) g_opt_mlp_split_shape = value;
     else if (!strcmp(name, "mlp_bf16_shape")) g_opt_mlp_bf16_shape = value;
     else if (!strcmp(name, "mlp_bwd_shape")) g_opt_bwd_shape = value;
+    else if (!strcmp(name, "mlp_rows128")) g_opt_mlp_rows128 = value;
     else {
         set_error("hgnn_set_option: unknown option '%s'", name);
         return HGNN_ERR_INVALID_ARG;

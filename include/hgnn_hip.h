@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 17
+#define HGNN_ABI_VERSION 18
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -115,6 +115,9 @@ int hgnn_sizeof_mlp_desc(void);
  *                  per-fragment waits, 2 one wait per k-chunk ("burst")
  *   "mlp_bwd_shape" fused bf16 backward layer, N = 512: 0 (default) 8 waves x 64 rows, 1 = 4 waves with the raw
  *                  z' tile reloaded per phase (A/B: spills, 6.2 vs 3.2 ms)
+ *   "mlp_rows128"  bf16 MLPs of latent 256 (K -> 512 (-> 512) -> 256): 0 (default) the feature-split kernel, 1 =
+ *                  hgnn_mlp_forward_bf16_rows128 (callers ask hgnn_mlp_rows128_enabled() to pick the weight layout;
+ *                  A/B: half the L2 weight traffic, same time -- the phase-locked epilogues eat the gain)
  *   "mlp_ablate"   DIAGNOSTIC bits, results are WRONG.  fp32 / bf16 kernels: 1 skip LayerNorm/act,
  *                  2 skip weight DMA, 4 skip barriers (tools/tune_mlp.py); feature-split bf16
  *                  kernel: 1 weights from chunk 0 only, 2 skip LayerNorm/act, 4 load only the first
@@ -325,6 +328,19 @@ int hgnn_mlp_forward_bf16(const hgnn_mlp_desc* d, void* out, hgnn_stream_t strea
  * forward of the bf16 training path. */
 int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d);
 int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
+
+/* bf16, latent 256 (K -> 512 (-> 512) -> 256, LayerNorm on every layer, every segment a multiple of 128 wide,
+ * n_pre = 0): ONE persistent workgroup of 8 waves per CU owns 128 rows, wave w an eighth of every layer's features for
+ * all 128 rows (v_mfma_f32_32x32x16_bf16), so a weight byte fetched from L2 serves 128 rows instead of the 64 of
+ * hgnn_mlp_forward_bf16_split, which is L2-bandwidth bound on its weight stream.  Same descriptor and arithmetic
+ * (gelu / tanh forms, fp32 LayerNorm, save_pre dumps as bf16 rows) as hgnn_mlp_forward_bf16_split, except the
+ * weight layout: W[l] (bf16) in the 32x32x16 A-FRAGMENT ORDER,
+ *   element index = ((s * (F/32) + T) * 64 + lane) * 8 + i  holds  W[32T + lane%32][16s + 8(lane/32) + i]
+ * (F = out features, s = 16-wide k-step, T = 32-feature tile, lane = 0..63, i = 0..7).
+ * hgnn_mlp_rows128_enabled: the "mlp_rows128" option (callers choose the weight layout by it). */
+int hgnn_mlp_supported_bf16_rows128(const hgnn_mlp_desc* d);
+int hgnn_mlp_forward_bf16_rows128(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
+int hgnn_mlp_rows128_enabled(void);
 
 /* LayerNorm + activation of one make_mlp layer (Modules/utils.py:169-196: Linear -> LayerNorm ->
  * act) over rows z[M, W] (the Linear's output, as dumped by hgnn_mlp_forward_f32's save_pre), one
