@@ -293,29 +293,67 @@ __global__ __launch_bounds__(NW * 64, MINB) void k_mlp_bf16_split(const Args a) 
     // ---------------- layer 1: B = input panels
     f32x4 acc1[NT1][NJ];
     init_bias<NT1, NJ>(acc1, a.b[0] + wave * NT1 * 16 + 4 * g);
-    // pre-projected gathered segments: row e starts at b + sum_s P_s[idx_s[e]] (this lane's 4 features per tile)
+    // pre-projected gathered segments: row e starts at b + sum_s P_s[idx_s[e]].  The P rows come in as WHOLE rows
+    // (16 bytes per lane, 16 rows per pass) through a ring of LDS buffers and are picked up in the accumulator layout from
+    // there: read straight from global memory that layout gives a lane 4 features of 16 different rows per instruction,
+    // 8-byte pieces that are issue-bound (round 1 measured the projected path SLOWER for that reason: 3.7 vs 2.7 ms).
     if (a.n_pre > 0) {
+        constexpr int HB = NT1 * NW * 32;          // bytes of a P row (= hidden width in bf16)
+        constexpr int PPR = HB / 16;               // 16-byte pieces per row
+        int32_t* pidx = (int32_t*)(red + NW * TE * 2);   // [2][TE] gather rows of this tile
+        for (int i = tid; i < 2 * TE; i += NTHR) {
+            const int sgm = i / TE;
+            long long e = e0 + (i % TE);
+            if (e >= a.M) e = a.M - 1;
+            const int r = sgm < a.n_pre ? a.pre_index[sgm][e] : 0;
+            pidx[i] = r < 0 ? 0 : r;
+        }
+        __syncthreads();
+        const int npass = a.n_pre * NJ;            // one 16-row tile of one segment per pass
+        // LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging registers) into a ring of four
+        // pass buffers, three passes in flight: with register staging the ring was one or two passes deep and every
+        // pass exposed most of a random-row HBM latency (projected 2.61-2.75 ms vs direct 2.77-2.83 ms)
+        constexpr int NPI = 16 * HB / 1024;        // DMA instructions per pass
+        constexpr int IPW = NPI / NW;              // ... per wave
+        static_assert(NPI % NW == 0 && 4 * 16 * HB <= REGION, "P staging ring does not fit");
+        auto pissue = [&](int p) {
+            const int sgm = p / NJ, j = p % NJ;
 #pragma unroll
-        for (int sgm = 0; sgm < 2; ++sgm) {
-            if (sgm < a.n_pre) {
+            for (int i = 0; i < IPW; ++i) {
+                const int k = wave + i * NW;                       // wave-uniform
+                const int gp = k * 64 + lane;
+                const int row = gp / PPR, pc = gp % PPR;
+                const int r = pidx[sgm * TE + 16 * j + row];
+                const char* src = (const char*)(a.pre_table[sgm] + (size_t)r * (HB / 2)) +
+                                  (((pc & ~15) | ((pc ^ row) & 15)) << 4);
+                dma_piece(src, lds_addr_of((float*)(smem + (p & 3) * 16 * HB)) + (unsigned)k * 1024u);
+            }
+        };
+        pissue(0);
+        if (npass > 1) pissue(1);
+        if (npass > 2) pissue(2);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    long long e = e0 + j * 16 + ei;
-                    if (e >= a.M) e = a.M - 1;
-                    const long long r = (long long)a.pre_index[sgm][e];
-                    const unsigned short* p = a.pre_table[sgm] + (size_t)(r < 0 ? 0 : r) * (size_t)(NT1 * NW * 16) +
-                                              (wave * NT1 * 16 + 4 * g);
+        for (int p = 0; p < 2 * NJ; ++p) {
+            if (p < npass) {
+                // this wave's pieces of pass p have landed once at most the younger passes' DMAs are outstanding
+                if (p + 2 < npass) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+                else if (p + 1 < npass) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();   // every wave's pieces; and every wave is past its reads of pass p - 1
+                const char* buf = smem + (p & 3) * 16 * HB + ei * HB + ((g & 1) << 3);
 #pragma unroll
-                    for (int t = 0; t < NT1; ++t) {
-                        const u16x4 v = *(const u16x4*)(p + t * 16);
-                        acc1[t][j].x += bf16_float(v[0]);
-                        acc1[t][j].y += bf16_float(v[1]);
-                        acc1[t][j].z += bf16_float(v[2]);
-                        acc1[t][j].w += bf16_float(v[3]);
-                    }
+                for (int t = 0; t < NT1; ++t) {
+                    const int q = 2 * (wave * NT1 + t) + (g >> 1);
+                    const u16x4 v = *(const u16x4*)(buf + (((q & ~15) | ((q ^ ei) & 15)) << 4));
+                    acc1[t][p % NJ].x += bf16_float(v[0]);
+                    acc1[t][p % NJ].y += bf16_float(v[1]);
+                    acc1[t][p % NJ].z += bf16_float(v[2]);
+                    acc1[t][p % NJ].w += bf16_float(v[3]);
                 }
+                if (p + 3 < npass) pissue(p + 3);   // into the buffer of pass p - 1
             }
         }
+        __syncthreads();   // the input panels reuse the buffers
     }
     {
         const int total = a.K1 / 32;
@@ -392,7 +430,7 @@ static int launch_act(const Args& a, hipStream_t s) {
     constexpr bool SWZ = NT1 * NW >= 32;
     constexpr int HRS = NT1 * NW * 32 + (SWZ ? 0 : 16);
     constexpr int PRS = PK * 2 + (SWZ ? 0 : 16);
-    const size_t lds_bytes = (size_t)cmax(TE * HRS, 2 * TE * PRS) + NW * TE * 2 * sizeof(float);
+    const size_t lds_bytes = (size_t)cmax(TE * HRS, 2 * TE * PRS) + NW * TE * 2 * sizeof(float) + 2 * TE * sizeof(int32_t);
     const unsigned grid = (unsigned)ceil_div(a.M, TE);
     auto kern = k_mlp_bf16_split<NT1, NT2, NT3, PK, ACT_H, ACT_O, MINB, VAR, NW, NJ>;
     if (lds_bytes > 64 * 1024) {
@@ -511,7 +549,7 @@ extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hg
     for (int s = 0; s < 2; ++s) {
         a.pre_table[s] = s < d->n_pre ? (const unsigned short*)d->pre_table[s] : nullptr;
         a.pre_index[s] = s < d->n_pre ? d->pre_index[s] : nullptr;
-        HGNN_REQUIRE((uintptr_t)a.pre_table[s] % 8 == 0, "hgnn_mlp_forward_bf16_split: pre_table[%d] must be 8-byte aligned", s);
+        HGNN_REQUIRE((uintptr_t)a.pre_table[s] % 16 == 0, "hgnn_mlp_forward_bf16_split: pre_table[%d] must be 16-byte aligned", s);
     }
     a.ablate = g_opt_mlp_ablate;
     for (int l = 0; l < 3; ++l) {

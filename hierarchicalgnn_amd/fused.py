@@ -73,7 +73,9 @@ _preproject = True
 # bf16 split kernel: implemented and parity-tested, but measured SLOWER (L=256: 3.7 vs 2.7 ms; L=512: 9.6 vs
 # 8.6 ms): the accumulator-layout gather of bf16 P rows is 32-byte pieces issued at the start of every
 # 64-row tile, which costs more than the 2/3 of the first layer's MFMAs it saves at 16x the matrix rate.
-_preproject_bf16 = False
+_preproject_bf16 = None   # bf16 feature-split kernel: None = by shape (first-layer width >= 512, i.e. latent >= 256:
+                          # kernel 2.33-2.42 vs 2.70-2.80 ms at latent 256, 7.1 vs 8.6 ms at latent 512 incl. the
+                          # projection GEMMs; latent 128 is 7 % slower projected), True / False = forced (A/B, tests)
 
 
 def set_preproject(flag: bool) -> None:
@@ -248,6 +250,32 @@ def _fragment_order32(W: torch.Tensor) -> torch.Tensor:
     return W.view(F // 32, 32, K // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
+_wcache = {}
+
+
+def _prepared_weight(weight, order, kept_cols):
+    """bf16 copy of a Linear weight (optionally only the column blocks of the segments that stay in the kernel's K
+    loop) in the kernel's fragment order, cached per (storage, version): an inference forward re-lays out nothing,
+    a training step once per optimizer update instead of once per call (forward + checkpoint recompute)"""
+    try:
+        ver = weight._version
+    except RuntimeError:          # inference tensors carry no version counter
+        ver = -1
+    key = (weight.data_ptr(), ver, tuple(weight.shape), order.__name__, kept_cols)
+    hit = _wcache.get(key) if ver >= 0 else None
+    if hit is not None and hit[0] is weight:
+        return hit[1]
+    W = weight.detach()
+    if kept_cols is not None:
+        W = torch.cat([W[:, c0:c1] for c0, c1 in kept_cols], dim=1)
+    W = order(W.to(torch.bfloat16).contiguous())
+    if ver >= 0:
+        if len(_wcache) > 1024:
+            _wcache.clear()
+        _wcache[key] = (weight, W)
+    return W
+
+
 def _rows128(widths, n_pre: int) -> bool:
     """latent-256 bf16 MLPs (K -> 512 (-> 512) -> 256) run on the 128-rows-per-weight-fetch kernel
     (hgnn_mlp_forward_bf16_rows128) after hgnn_set_option("mlp_rows128", 1) (A/B option: measured equal to the
@@ -316,7 +344,11 @@ def _descriptor_bf16(net, segments, skip, split=False, dry=False):
     lin0 = layers[0][0]
     if lin0.in_features != sum(int(t.shape[1]) for t, _ in segments) or not lin0.weight.is_cuda:
         return None
-    proj = _projected_segments(segments, M) if (split and _preproject_bf16) else []
+    want_pre = _preproject_bf16
+    if want_pre is None:
+        widths = [lin.out_features for lin, _, _ in layers]
+        want_pre = len(layers) > 1 and lin0.out_features >= 512 and not _rows128(widths, 0)
+    proj = _projected_segments(segments, M) if (split and want_pre) else []
     col = n_kept = n_pre = 0
     kept_cols = []
     for i, (table, index) in enumerate(segments):
@@ -332,7 +364,8 @@ def _descriptor_bf16(net, segments, skip, split=False, dry=False):
                 P = t
             else:
                 with torch.autocast("cuda", enabled=False):
-                    P = torch.matmul(t.float(), lin0.weight.detach()[:, col:col + w].float().t()).to(torch.bfloat16)
+                    # bf16 operands, fp32 accumulation, one rounding: the arithmetic the kernel's own MFMAs would do
+                    P = torch.matmul(t, lin0.weight.detach()[:, col:col + w].to(torch.bfloat16).t())
                 keep.append(P)
             d.pre_table[n_pre] = P.data_ptr()
             d.pre_index[n_pre] = i32.data_ptr() if i32.numel() else None
@@ -355,12 +388,12 @@ def _descriptor_bf16(net, segments, skip, split=False, dry=False):
         if (l > 0 and lin.in_features != d.width[l]) or not lin.weight.is_cuda:
             return None
         W = lin.weight.detach()
-        if l == 0 and n_pre and not dry:
-            W = torch.cat([W[:, c0:c1] for c0, c1 in kept_cols], dim=1)
         if split:
-            if W.shape[1] % 32 or lin.out_features % 64:
+            k_in = sum(c1 - c0 for c0, c1 in kept_cols) if (l == 0 and n_pre) else W.shape[1]
+            if k_in % 32 or lin.out_features % 64:
                 return None
-            W = W if dry else order(W.to(torch.bfloat16).contiguous())
+            if not dry:
+                W = _prepared_weight(lin.weight, order, tuple(kept_cols) if (l == 0 and n_pre) else None)
         else:
             if l > 0:
                 if lin.in_features % 32:

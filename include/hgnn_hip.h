@@ -281,7 +281,7 @@ typedef struct hgnn_mlp_desc {
                                   * hand P_s here: the kernel starts row e's accumulators at
                                   * b + sum_s P_s[pre_index[s][e]].  For nodes[graph[k]] (N rows, M = 16.7 N
                                   * edges) this removes 2/3 of the edge network's first-layer FLOPs.  */
-    const float* pre_table[2];   /* [rows_s, width[1]], 16-byte aligned (bf16 rows, 8-byte aligned, for
+    const float* pre_table[2];   /* [rows_s, width[1]], 16-byte aligned (bf16 rows for
                                   * hgnn_mlp_forward_bf16_split)                    */
     const int32_t* pre_index[2]; /* int32[M]                                      */
 } hgnn_mlp_desc;

@@ -91,7 +91,7 @@ def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M, split):
     from hierarchicalgnn_amd import _lib, fused, make_mlp
     shape1 = split == "shape1"
     rows128 = split == "rows128"
-    fused._preproject_bf16 = split == "preproject"
+    fused._preproject_bf16 = split == "preproject"      # (forced on / off: the default decides by shape)
     split = bool(split)
     fused.set_bf16_split(split)
     _lib.load().hgnn_set_option(b"mlp_split_shape", 1 if shape1 else 0)
@@ -126,7 +126,7 @@ def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M, split):
             out = fused.fused_concat_mlp(net, segs, segs[-1][0])
     finally:
         fused.set_bf16_split(True)
-        fused._preproject_bf16 = False
+        fused._preproject_bf16 = None
         _lib.load().hgnn_set_option(b"mlp_split_shape", -1)
         _lib.load().hgnn_set_option(b"mlp_rows128", 0)
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
