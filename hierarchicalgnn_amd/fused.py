@@ -261,18 +261,18 @@ def _prepared_weight(weight, order, kept_cols):
         ver = weight._version
     except RuntimeError:          # inference tensors carry no version counter
         ver = -1
-    key = (weight.data_ptr(), ver, tuple(weight.shape), order.__name__, kept_cols)
+    key = (weight.data_ptr(), tuple(weight.shape), order.__name__, kept_cols)
     hit = _wcache.get(key) if ver >= 0 else None
-    if hit is not None and hit[0] is weight:
-        return hit[1]
+    if hit is not None and hit[0] is weight and hit[1] == ver:
+        return hit[2]
     W = weight.detach()
     if kept_cols is not None:
         W = torch.cat([W[:, c0:c1] for c0, c1 in kept_cols], dim=1)
     W = order(W.to(torch.bfloat16).contiguous())
     if ver >= 0:
-        if len(_wcache) > 1024:
+        if len(_wcache) > 4096:
             _wcache.clear()
-        _wcache[key] = (weight, W)
+        _wcache[key] = (weight, ver, W)     # one prepared copy per weight: a new version replaces the old one
     return W
 
 
