@@ -1,0 +1,485 @@
+// fp32 fused  gather -> concat -> [Linear -> LayerNorm -> act] x {2,3} -> (+skip)  MLP whose GEMMs run on the bf16
+// matrix pipe as SPLIT-bf16 products (opt-in: hgnn_mlp_forward_f32_split3).
+//
+// Every fp32 operand is written as  x = hi + mid (+ lo),  hi = bf16(x), mid = bf16(x - hi): 8 + 8 significand bits.
+// Products of bf16 parts are exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates them in fp32, so
+//     x . w  ~=  hi.hi + mid.hi + hi.mid          (dropped: mid.mid and the lo terms, ~2^-16 relative)
+// costs 3 bf16 MFMAs = 3/16 of the time of the one fp32 MFMA (v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate).
+// Error budget, measured against the REFERENCE's scores on BASELINE config 2 (tests/test_split_bf16_study.py, oracle
+// arithmetic): 2.0e-5 at model level, 5x inside the 1e-4 bar; bias, LayerNorm, activations (exact-erf GELU), skip and
+// all rows in HBM stay fp32.
+//
+// Decomposition = the bf16 feature-split kernel's (mlp_split_bf16.hip): a workgroup of 8 waves owns 64 rows, wave w an
+// eighth of every layer's features; weights stream from L2 in A-fragment order through the register ring (gemm_lds).
+// What changes:
+//   * input rows are fp32 in HBM; a 128-wide k-panel is split into a hi and a mid bf16 plane while it is written to
+//     LDS; per 32-wide k-chunk the loop issues  W_mid.x_hi, W_hi.x_mid, W_hi.x_hi  (small terms first) from ONE fetch of
+//     the chunk's W_hi and W_mid fragments -- the host interleaves them per chunk (fused._split3_weight);
+//   * hidden rows are kept as two bf16 planes (hi, mid) in LDS, the hidden layers' GEMMs run the same loop;
+//   * gathered node segments arrive pre-projected in fp32 (hgnn_mlp_desc.n_pre, exact fp32 library GEMMs) as whole
+//     rows by LDS-DMA, as in the bf16 kernel;
+//   * output / skip rows are fp32 (16 bytes per lane and tile).
+#include "mlp_split_common.h"
+
+namespace hgnn {
+namespace f3 {
+using namespace fs;
+
+struct Args {
+    const float* seg_table[3];
+    const int32_t* seg_index[3];
+    int seg_width[3];
+    int n_seg;
+    int K1;
+    const unsigned short* W[3];  // bf16 split-3 stream in A-fragment order (see header)
+    const float* b[3];
+    const float* lnw[3];
+    const float* lnb[3];
+    int act[3];
+    float eps;
+    const float* skip;
+    float* out;
+    long long M;
+    const float* pre_table[2];
+    const int32_t* pre_index[2];
+    int n_pre;
+};
+
+constexpr int NJ = 4;
+constexpr int TE = 64;
+constexpr int PK = 128;
+constexpr int PRS = PK * 2 + 16;   // bf16 panel row stride (padded: 2-way conflicts at most)
+constexpr int PANEL = TE * PRS;
+constexpr int CPP = PK / 32;
+
+// (hi, mid) planes of 4 fp32 values
+__device__ __forceinline__ void split4(const f32x4 v, u16x4& h, u16x4& m) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned short hb = bf16_bits(v[c]);
+        h[c] = hb;
+        m[c] = bf16_bits(v[c] - bf16_float(hb));
+    }
+}
+
+// bias -> LayerNorm over ALL features of the layer -> activation (exact-erf GELU: this is the fp32 parity path)
+template <int NT, int NW>
+__device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT][NJ], const float* __restrict__ lnw,
+                                              const float* __restrict__ lnb, int act, float eps, float* red, int wave,
+                                              int ei, int g) {
+    constexpr float inv_n = 1.0f / (float)(NW * NT * 16);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 v = acc[t][j];
+            s += (v.x + v.y) + (v.z + v.w);
+            q = fmaf(v.x, v.x, q);
+            q = fmaf(v.y, v.y, q);
+            q = fmaf(v.z, v.z, q);
+            q = fmaf(v.w, v.w, q);
+        }
+        s += __shfl_xor(s, 16);
+        q += __shfl_xor(q, 16);
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (g == 0) {
+            f32x2 sq;
+            sq.x = s;
+            sq.y = q;
+            *(f32x2*)(red + (wave * TE + j * 16 + ei) * 2) = sq;
+        }
+    }
+    __syncthreads();
+    float rstd[NJ], shift[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const f32x2 sq = *(const f32x2*)(red + (w * TE + j * 16 + ei) * 2);
+            s += sq.x;
+            q += sq.y;
+        }
+        const float mean = s * inv_n;
+        const float var = fmaxf(fmaf(-mean, mean, q * inv_n), 0.f);
+        rstd[j] = 1.0f / sqrtf(var + eps);
+        shift[j] = -mean * rstd[j];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 w4 = *(const f32x4*)(lnw + t * 16);
+        const f32x4 b4 = *(const f32x4*)(lnb + t * 16);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f32x4 v = acc[t][j];
+            v.x = act_apply(fmaf(fmaf(v.x, rstd[j], shift[j]), w4.x, b4.x), act);
+            v.y = act_apply(fmaf(fmaf(v.y, rstd[j], shift[j]), w4.y, b4.y), act);
+            v.z = act_apply(fmaf(fmaf(v.z, rstd[j], shift[j]), w4.z, b4.z), act);
+            v.w = act_apply(fmaf(fmaf(v.w, rstd[j], shift[j]), w4.w, b4.w), act);
+            acc[t][j] = v;
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void init_bias(f32x4 (&acc)[NT][NJ], const float* __restrict__ b) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 bv = *(const f32x4*)(b + t * 16);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[t][j] = bv;
+    }
+}
+
+// activated tile -> the hi and mid bf16 planes of the hidden rows (plane stride PLB bytes, row stride HRS)
+template <int NT, int HRS, int PLB>
+__device__ __forceinline__ void write_hidden2(const f32x4 (&acc)[NT][NJ], char* smem, int wave, int ei, int g) {
+    char* lane0 = smem + ei * HRS + ((2 * wave * NT) << 4) + (g << 3);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            u16x4 h, m;
+            split4(acc[t][j], h, m);
+            *(u16x4*)(lane0 + j * 16 * HRS + t * 32) = h;
+            *(u16x4*)(lane0 + PLB + j * 16 * HRS + t * 32) = m;
+        }
+    }
+}
+
+// acc += x_hi.W_hi + x_mid.W_hi + x_hi.W_mid over n real 32-wide k-chunks.  The weight stream holds, per real chunk,
+// the W_hi fragments followed by the W_mid fragments (virtual chunks 2c, 2c + 1: fused._split3_weight), so a W_hi
+// fragment is fetched ONCE and feeds both operand planes (the first version streamed [W_hi | W_hi | W_mid] through
+// three passes of the bf16 kernel's loop: 1.5 MiB of L2 reads per 64-row tile, L2-bound at 8.0 ms; now 1.0 MiB).
+// Everything is double-buffered one chunk ahead: a chunk is 3 NT NJ MFMAs (768 cycles at NT = 4).
+template <int NT, int RS, int NW>
+__device__ __forceinline__ void gemm3s(f32x4 (&acc)[NT][NJ], const u16x8* __restrict__ wp, int gv0, int vtotal,
+                                       const char* b_hi, const char* b_mid, int n) {
+    constexpr int VS = NW * NT * 64;   // u16x8 units per virtual chunk
+    u16x8 wh[2][NT], wm[2][NT], bh[2][NJ], bm[2][NJ];
+    auto loadw = [&](int c, int sl) {
+        int v = gv0 + 2 * c;
+        if (v + 1 >= vtotal) v = vtotal - 2;
+        const u16x8* p = wp + (size_t)v * VS;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            wh[sl][t] = p[t * 64];
+            wm[sl][t] = p[VS + t * 64];
+        }
+    };
+    auto loadb = [&](int c, int sl) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bh[sl][j] = *(const u16x8*)(b_hi + j * 16 * RS + c * 64);
+            bm[sl][j] = *(const u16x8*)(b_mid + j * 16 * RS + c * 64);
+        }
+    };
+    loadw(0, 0);
+    loadb(0, 0);
+    for (int c = 0; c < n; c += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cn = c + u + 1 < n ? c + u + 1 : n - 1;
+            loadw(cn, (u + 1) & 1);
+            loadb(cn, (u + 1) & 1);
+            // keep the next chunk's loads AHEAD of this chunk's MFMAs (hipcc otherwise sinks them to their first use)
+            __builtin_amdgcn_sched_group_barrier(0x020, 2 * NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NJ, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(wm[u][t]), as_bf16(bh[u][j]), acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(wh[u][t]), as_bf16(bm[u][j]), acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(wh[u][t]), as_bf16(bh[u][j]), acc[t][j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT * NJ, 0);
+        }
+    }
+}
+
+// NW waves share the 64 rows (8: two per SIMD; 16: four per SIMD -- at latent 256 the two bf16 planes of the hidden
+// rows leave room for ONE workgroup per CU, whose waves are phase-locked by the barriers: more of them hide more
+// latency); NTH / NTO: 16-feature tiles per wave of the hidden / output layers; NL = 2 or 3 layers
+template <int NW, int NTH, int NTO, int NL>
+__global__ __launch_bounds__(NW * 64, 1) void k_mlp_f32_split3(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTHR = NW * 64;
+    constexpr int H = NTH * NW * 16;
+    constexpr int O = NTO * NW * 16;
+    constexpr int HRS = H * 2 + 16;            // hidden row stride of one plane (padded)
+    constexpr int PLB = TE * HRS;              // bytes of one hidden plane
+    constexpr int PHB = H * 4;                 // bytes of an fp32 P row
+    constexpr int REGION = cmax(cmax(2 * PLB, 4 * PANEL), 4 * 16 * PHB);
+    constexpr int NC = H / 32;                 // k-chunks of a hidden layer (per plane)
+    float* red = (float*)(smem + REGION);                 // [NW][TE][sum, sumsq]
+    int32_t* pidx = (int32_t*)(red + NW * TE * 2);        // [2][TE]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ei = lane & 15;
+    const int g = lane >> 4;
+    const long long e0 = (long long)blockIdx.x * TE;
+
+    // ---- input panels: 32 threads move one row's 128 fp32 (16 bytes each), 16 rows per pass
+    constexpr int LPR = PK * 4 / 16;   // 32
+    constexpr int RPP = NTHR / LPR;    // 16
+    constexpr int NP = TE / RPP;       // 4
+    const int prow = tid / LPR;
+    const int pcol = tid % LPR;
+    const float* px[NP];
+    int r1[NP], r2[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        long long e = e0 + i * RPP + prow;
+        if (e >= a.M) e = a.M - 1;
+        long long r0 = a.seg_index[0] != nullptr ? (long long)a.seg_index[0][e] : e;
+        if (r0 < 0) r0 = 0;
+        px[i] = a.seg_table[0] + (size_t)r0 * (size_t)a.seg_width[0] + pcol * 4;
+        r1[i] = a.n_seg > 1 ? (a.seg_index[1] != nullptr ? a.seg_index[1][e] : (int)e) : 0;
+        r2[i] = a.n_seg > 2 ? (a.seg_index[2] != nullptr ? a.seg_index[2][e] : (int)e) : 0;
+        if (r1[i] < 0) r1[i] = 0;
+        if (r2[i] < 0) r2[i] = 0;
+    }
+    const int np = a.K1 / PK;
+    const int p1 = a.seg_width[0] / PK;
+    const int p2 = p1 + (a.n_seg > 1 ? a.seg_width[1] / PK : np);
+    f32x4 st[NP];
+    int pl = 0;
+    auto load_panel = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            st[i] = *(const f32x4*)px[i];
+            px[i] += PK;
+        }
+        ++pl;
+        if (pl == p1) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) px[i] = a.seg_table[1] + (size_t)r1[i] * (size_t)a.seg_width[1] + pcol * 4;
+        }
+        if (pl == p2) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) px[i] = a.seg_table[2] + (size_t)r2[i] * (size_t)a.seg_width[2] + pcol * 4;
+        }
+    };
+    auto store_panel = [&](int buf) {   // buffers 2 buf (hi) and 2 buf + 1 (mid)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            u16x4 h, m;
+            split4(st[i], h, m);
+            char* dst = smem + (2 * buf) * PANEL + (i * RPP + prow) * PRS + pcol * 8;
+            *(u16x4*)dst = h;
+            *(u16x4*)(dst + PANEL) = m;
+        }
+    };
+
+    // ---------------- layer 1
+    f32x4 acc1[NTH][NJ];
+    init_bias<NTH>(acc1, a.b[0] + wave * NTH * 16 + 4 * g);
+    // the first input panel is requested BEFORE the pre-projected rows: it is older in the in-order vector-memory
+    // queue, so the counted waits of the DMA ring below stay exact, and its latency hides under the P phase
+    const int vtotal = 2 * (a.K1 / 32);
+    const u16x8* wp = (const u16x8*)a.W[0] + (size_t)(wave * NTH) * 64 + lane;
+    load_panel();
+    if (a.n_pre > 0) {
+        // pre-projected gathered segments (fp32 rows): whole rows by LDS-DMA through a ring of four 16-row buffers,
+        // added in the accumulator layout from LDS (see mlp_split_bf16.hip)
+        constexpr int PPR = PHB / 16;
+        constexpr int NPI = 16 * PHB / 1024;
+        constexpr int IPW = NPI / NW;
+        static_assert(NPI % NW == 0, "P pass does not split over the waves");
+        for (int i = tid; i < 2 * TE; i += NTHR) {
+            const int sgm = i / TE;
+            long long e = e0 + (i % TE);
+            if (e >= a.M) e = a.M - 1;
+            const int r = sgm < a.n_pre ? a.pre_index[sgm][e] : 0;
+            pidx[i] = r < 0 ? 0 : r;
+        }
+        __syncthreads();
+        const int npass = a.n_pre * NJ;
+        auto pissue = [&](int p) {
+            const int sgm = p / NJ, j = p % NJ;
+#pragma unroll
+            for (int i = 0; i < IPW; ++i) {
+                const int k = wave + i * NW;
+                const int gp = k * 64 + lane;
+                const int row = gp / PPR, pc = gp % PPR;
+                const int r = pidx[sgm * TE + 16 * j + row];
+                const char* src = (const char*)(a.pre_table[sgm] + (size_t)r * H) + (((pc & ~15) | ((pc ^ row) & 15)) << 4);
+                dma_piece(src, lds_addr_of((float*)(smem + (p & 3) * 16 * PHB)) + (unsigned)k * 1024u);
+            }
+        };
+        pissue(0);
+        if (npass > 1) pissue(1);
+        if (npass > 2) pissue(2);
+#pragma unroll
+        for (int p = 0; p < 2 * NJ; ++p) {
+            if (p < npass) {
+                if (p + 2 < npass) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+                else if (p + 1 < npass) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const char* buf = smem + (p & 3) * 16 * PHB + ei * PHB;
+#pragma unroll
+                for (int t = 0; t < NTH; ++t) {
+                    const int q = 4 * (wave * NTH + t) + g;
+                    acc1[t][p % NJ] += *(const f32x4*)(buf + (((q & ~15) | ((q ^ ei) & 15)) << 4));
+                }
+                if (p + 3 < npass) pissue(p + 3);
+            }
+        }
+        __syncthreads();
+    }
+    {
+        store_panel(0);
+        __syncthreads();
+        const char* blane = smem + ei * PRS + (g << 4);
+        for (int p = 0; p < np; ++p) {
+            const bool more = p + 1 < np;
+            if (more) load_panel();
+            const char* bh = blane + (2 * (p & 1)) * PANEL;
+            gemm3s<NTH, PRS, NW>(acc1, wp, 2 * p * CPP, vtotal, bh, bh + PANEL, CPP);
+            if (more) store_panel((p + 1) & 1);
+            __syncthreads();
+        }
+    }
+    layernorm_act<NTH, NW>(acc1, a.lnw[0] + wave * NTH * 16 + 4 * g, a.lnb[0] + wave * NTH * 16 + 4 * g, a.act[0], a.eps, red,
+                       wave, ei, g);
+    // (the barrier inside layernorm_act also means: every wave is done reading the panels)
+    write_hidden2<NTH, HRS, PLB>(acc1, smem, wave, ei, g);
+    __syncthreads();
+    const char* hlane = smem + ei * HRS + (g << 4);
+    if constexpr (NL == 3) {
+        // ---------------- middle layer (same width), hidden planes rewritten in place
+        init_bias<NTH>(acc1, a.b[1] + wave * NTH * 16 + 4 * g);
+        {
+            const u16x8* wp1 = (const u16x8*)a.W[1] + (size_t)(wave * NTH) * 64 + lane;
+            gemm3s<NTH, HRS, NW>(acc1, wp1, 0, 2 * NC, hlane, hlane + PLB, NC);
+        }
+        layernorm_act<NTH, NW>(acc1, a.lnw[1] + wave * NTH * 16 + 4 * g, a.lnb[1] + wave * NTH * 16 + 4 * g, a.act[1], a.eps,
+                           red, wave, ei, g);
+        write_hidden2<NTH, HRS, PLB>(acc1, smem, wave, ei, g);   // (barrier inside layernorm_act: all reads done)
+        __syncthreads();
+    }
+    // ---------------- output layer
+    constexpr int LO = NL - 1;
+    f32x4 acc2[NTO][NJ];
+    init_bias<NTO>(acc2, a.b[LO] + wave * NTO * 16 + 4 * g);
+    {
+        const u16x8* wpo = (const u16x8*)a.W[LO] + (size_t)(wave * NTO) * 64 + lane;
+        gemm3s<NTO, HRS, NW>(acc2, wpo, 0, 2 * NC, hlane, hlane + PLB, NC);
+    }
+    layernorm_act<NTO, NW>(acc2, a.lnw[LO] + wave * NTO * 16 + 4 * g, a.lnb[LO] + wave * NTO * 16 + 4 * g, a.act[LO], a.eps,
+                       red, wave, ei, g);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long e = e0 + j * 16 + ei;
+        if (e >= a.M) continue;
+        const size_t off = (size_t)e * O + (size_t)(wave * NTO * 16 + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) {
+            f32x4 v = acc2[t][j];
+            if (a.skip != nullptr) v += *(const f32x4*)(a.skip + off + t * 16);
+            *(f32x4*)(a.out + off + t * 16) = v;
+        }
+    }
+}
+
+template <int NW, int NTH, int NTO, int NL>
+static int launch(const Args& a, hipStream_t s) {
+    constexpr int NTHR = NW * 64;
+    constexpr int H = NTH * NW * 16;
+    constexpr int HRS = H * 2 + 16;
+    constexpr int REGION = cmax(cmax(2 * TE * HRS, 4 * PANEL), 4 * 16 * H * 4);
+    const size_t lds_bytes = (size_t)REGION + NW * TE * 2 * sizeof(float) + 2 * TE * sizeof(int32_t);
+    const unsigned grid = (unsigned)ceil_div(a.M, TE);
+    auto kern = k_mlp_f32_split3<NW, NTH, NTO, NL>;
+    HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    kern<<<grid, NTHR, lds_bytes, s>>>(a);
+    HGNN_CHECK_HIP(hipGetLastError());
+    return HGNN_OK;
+}
+
+}  // namespace f3
+}  // namespace hgnn
+
+using namespace hgnn;
+
+extern "C" int hgnn_mlp_supported_f32_split3(const hgnn_mlp_desc* d) {
+    if (d == nullptr) return 0;
+    if (d->n_seg < 1 || d->n_seg > 3 || d->n_layers < 2 || d->n_layers > 3) return 0;
+    int k = 0;
+    for (int s = 0; s < d->n_seg; ++s) {
+        if (d->seg_width[s] <= 0 || d->seg_width[s] % 128 != 0) return 0;
+        k += d->seg_width[s];
+    }
+    if (k != d->width[0] || d->w0_cols != 0 || d->w_last_rows != 0) return 0;
+    const int n = d->n_layers;
+    for (int l = 0; l < n; ++l)
+        if (d->W[l] == nullptr || d->b[l] == nullptr || d->ln_w[l] == nullptr || d->ln_b[l] == nullptr) return 0;
+    for (int l = 0; l < 3; ++l)
+        if (d->save_pre[l] != nullptr) return 0;   // inference forward only
+    if (d->n_pre < 0 || d->n_pre > 2) return 0;
+    for (int s = 0; s < d->n_pre; ++s)
+        if (d->pre_table[s] == nullptr || d->pre_index[s] == nullptr) return 0;
+    if (d->M < 0 || d->M > 0x7fffffffLL) return 0;
+    const int h = d->width[1], o = d->width[n];
+    if (n == 3 && d->width[2] != h) return 0;
+    if (h != 2 * o) return 0;
+    return (o == 128 || o == 256) ? 1 : 0;
+}
+
+extern "C" int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, hgnn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HGNN_REQUIRE(d != nullptr && out != nullptr, "hgnn_mlp_forward_f32_split3: NULL argument");
+    if (!hgnn_mlp_supported_f32_split3(d)) {
+        set_error("hgnn_mlp_forward_f32_split3: unsupported shape (K -> 2L (-> 2L) -> L, L in {128, 256}, LayerNorm on "
+                  "every layer, every segment a multiple of 128 wide, no save_pre)");
+        return HGNN_ERR_UNSUPPORTED;
+    }
+    if (d->M == 0) return HGNN_OK;
+    f3::Args a;
+    for (int s = 0; s < 3; ++s) {
+        const bool on = s < d->n_seg;
+        a.seg_table[s] = on ? d->seg_table[s] : d->seg_table[0];
+        a.seg_index[s] = on ? d->seg_index[s] : nullptr;
+        a.seg_width[s] = on ? d->seg_width[s] : 0;
+        if (on) {
+            HGNN_REQUIRE(a.seg_table[s] != nullptr && (uintptr_t)a.seg_table[s] % 16 == 0,
+                         "hgnn_mlp_forward_f32_split3: segment table %d is NULL or not 16-byte aligned", s);
+        }
+    }
+    a.n_seg = d->n_seg;
+    a.K1 = d->width[0];
+    for (int l = 0; l < 3; ++l) {
+        const bool on = l < d->n_layers;
+        a.W[l] = on ? (const unsigned short*)d->W[l] : nullptr;
+        a.b[l] = on ? d->b[l] : nullptr;
+        a.lnw[l] = on ? d->ln_w[l] : nullptr;
+        a.lnb[l] = on ? d->ln_b[l] : nullptr;
+        a.act[l] = on ? d->act[l] : 0;
+        if (on) {
+            HGNN_REQUIRE((uintptr_t)a.W[l] % 16 == 0 && (uintptr_t)a.b[l] % 16 == 0 &&
+                             (uintptr_t)a.lnw[l] % 16 == 0 && (uintptr_t)a.lnb[l] % 16 == 0,
+                         "hgnn_mlp_forward_f32_split3: layer %d parameters must be 16-byte aligned", l);
+        }
+    }
+    a.eps = d->ln_eps;
+    a.skip = d->skip;
+    a.out = out;
+    a.M = d->M;
+    a.n_pre = d->n_pre;
+    for (int s = 0; s < 2; ++s) {
+        a.pre_table[s] = s < d->n_pre ? d->pre_table[s] : nullptr;
+        a.pre_index[s] = s < d->n_pre ? d->pre_index[s] : nullptr;
+        HGNN_REQUIRE((uintptr_t)a.pre_table[s] % 16 == 0, "hgnn_mlp_forward_f32_split3: pre_table[%d] must be 16-byte aligned", s);
+    }
+    HGNN_REQUIRE((uintptr_t)out % 16 == 0 && (uintptr_t)a.skip % 16 == 0,
+                 "hgnn_mlp_forward_f32_split3: out/skip must be 16-byte aligned");
+    const int o = d->width[d->n_layers];
+    if (d->n_layers == 2) return o == 256 ? f3::launch<8, 4, 2, 2>(a, stream) : f3::launch<8, 2, 1, 2>(a, stream);
+    return o == 256 ? f3::launch<8, 4, 2, 3>(a, stream) : f3::launch<8, 2, 1, 3>(a, stream);
+}

@@ -15,6 +15,7 @@ cover take the library path.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -299,6 +300,76 @@ def _split_forward(d, out, dev):
                    "hgnn_mlp_forward_bf16_split")
 
 
+_fp32_split3 = os.environ.get("HGNN_FP32_SPLIT3", "0") == "1"
+
+
+def set_fp32_split3(flag: bool) -> None:
+    """opt-in: inference forwards of the fp32 MLPs at latent 128 / 256 evaluate their GEMMs as split-bf16 products on the
+    bf16 matrix pipe (hgnn_mlp_forward_f32_split3: hi.hi + mid.hi + hi.mid, exact products, fp32 accumulation;
+    2e-5 at model level against the reference on BASELINE config 2, inside north_star's 1e-4).  Default off: the
+    default fp32 path is the exact fp32 matrix instruction."""
+    global _fp32_split3
+    _fp32_split3 = bool(flag)
+
+
+def _split3_weight(weight, kept_cols, panels: bool):
+    """bf16 split stream of an fp32 Linear weight (per 32-wide k-chunk of the kept columns: W_hi, then W_mid) in
+    A-fragment order, cached per weight version"""
+    try:
+        ver = weight._version
+    except RuntimeError:
+        ver = -1
+    key = (weight.data_ptr(), tuple(weight.shape), "split3", kept_cols, panels)
+    hit = _wcache.get(key) if ver >= 0 else None
+    if hit is not None and hit[0] is weight and hit[1] == ver:
+        return hit[2]
+    W = weight.detach().float()
+    if kept_cols is not None:
+        W = torch.cat([W[:, c0:c1] for c0, c1 in kept_cols], dim=1)
+    hi = W.to(torch.bfloat16)
+    mid = (W - hi.float()).to(torch.bfloat16)
+    F, K = W.shape
+    # per 32-wide k-chunk: the chunk's W_hi columns, then its W_mid columns (virtual chunks 2c, 2c + 1)
+    Wv = torch.stack([hi.view(F, K // 32, 32), mid.view(F, K // 32, 32)], dim=2).reshape(F, 2 * K)
+    Wv = _fragment_order(Wv.contiguous())
+    if ver >= 0:
+        if len(_wcache) > 4096:
+            _wcache.clear()
+        _wcache[key] = (weight, ver, Wv)
+    return Wv
+
+
+def _try_split3(net, segments, d, keep):
+    """re-point a ready fp32 descriptor at split-3 weight streams if the opt-in path supports its shape"""
+    if not _fp32_split3:
+        return False
+    layers = _parse(net)
+    if layers is None or len(layers) not in (2, 3) or any(ln is None for _, ln, _ in layers):
+        return False
+    if int(d.w0_cols) != 0 or int(d.w_last_rows) != 0 or any(int(d.seg_width[i]) % 128 for i in range(int(d.n_seg))):
+        return False
+    o = layers[-1][0].out_features
+    if o not in (128, 256) or any(lin.out_features != 2 * o for lin, _, _ in layers[:-1]):
+        return False
+    kept = None
+    if int(d.n_pre):
+        # the columns of the segments that stayed in the kernel's K loop, in order
+        col, kept, proj = 0, [], _projected_segments(segments, int(d.M))
+        for i, (t, _) in enumerate(segments):
+            w = int(t.shape[1])
+            if i not in proj:
+                kept.append((col, col + w))
+            col += w
+        kept = tuple(kept)
+    for l, (lin, _, _) in enumerate(layers):
+        W = _split3_weight(lin.weight, kept if l == 0 else None, l == 0)
+        keep.append(W)
+        d.W[l] = W.data_ptr()
+    if not bool(_lib.load().hgnn_mlp_supported_f32_split3(ctypes.byref(d))):
+        raise RuntimeError("fused_concat_mlp: split-3 descriptor rejected")
+    return True
+
+
 _bf16_split = True
 
 
@@ -543,6 +614,10 @@ def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
         elif bf16:
             _lib.check(lib.hgnn_mlp_forward_bf16(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
                        "hgnn_mlp_forward_bf16")
+        elif _try_split3(net, segments, d, keep):
+            _lib.check(lib.hgnn_mlp_forward_f32_split3(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
+                       "hgnn_mlp_forward_f32_split3")
+            stats["split3_calls"] = stats.get("split3_calls", 0) + 1
         else:
             _lib.check(lib.hgnn_mlp_forward_f32(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
                        "hgnn_mlp_forward_f32")

@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 18
+#define HGNN_ABI_VERSION 19
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -341,6 +341,19 @@ int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hgnn_stream_t
 int hgnn_mlp_supported_bf16_rows128(const hgnn_mlp_desc* d);
 int hgnn_mlp_forward_bf16_rows128(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
 int hgnn_mlp_rows128_enabled(void);
+
+/* fp32 rows, SPLIT-bf16 arithmetic (opt-in fast path of the fp32 MLPs at latent 128 / 256: K -> 2L (-> 2L) -> L,
+ * LayerNorm on every layer, every segment a multiple of 128 wide, n_pre allowed, no save_pre): every fp32 operand of
+ * the GEMMs is used as hi + mid with hi = bf16(x), mid = bf16(x - hi), and  x.w ~= hi.hi + mid.hi + hi.mid  runs as
+ * three v_mfma_f32_16x16x32_bf16 (exact products, fp32 accumulation) instead of one fp32 MFMA at 1/16 of the rate.
+ * Bias, LayerNorm, exact-erf GELU / tanh, skip and every row in HBM stay fp32.  Error at model level 2e-5 against the
+ * reference's scores on BASELINE config 2 (north_star's bar: 1e-4).  Same descriptor as hgnn_mlp_forward_f32 (fp32
+ * segment tables, fp32 pre_table rows of width[1] floats, fp32 skip / out), except W[l]: bf16, the layer's split
+ * stream -- per 32-wide k-chunk c of the (kept) input columns the chunk's W_hi columns followed by its W_mid columns,
+ * i.e. a [out, 2 K] matrix whose 32-column chunks 2c / 2c + 1 are hi / mid -- in the A-fragment order of
+ * hgnn_mlp_forward_bf16_split. */
+int hgnn_mlp_supported_f32_split3(const hgnn_mlp_desc* d);
+int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, hgnn_stream_t stream);
 
 /* LayerNorm + activation of one make_mlp layer (Modules/utils.py:169-196: Linear -> LayerNorm ->
  * act) over rows z[M, W] (the Linear's output, as dumped by hgnn_mlp_forward_f32's save_pre), one

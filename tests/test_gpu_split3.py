@@ -1,0 +1,75 @@
+"""Opt-in fast path of the fp32 MLPs (hgnn_mlp_forward_f32_split3): fp32 rows, GEMMs as split-bf16 products
+(hi.hi + mid.hi + hi.mid on the bf16 matrix pipe, fp32 accumulation).  Bars: a single MLP within 2e-5 of an fp64
+evaluation; BASELINE configs 2 and 3 at model level within north_star's 1e-4 of the REFERENCE's outputs (the same
+fixtures and checks as the exact fp32 path, tests/test_gpu_configs.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_parity, load_golden
+import test_gpu_configs as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def split3():
+    from hierarchicalgnn_amd import fused
+    fused.set_fp32_split3(True)
+    yield fused
+    fused.set_fp32_split3(False)
+
+
+@pytest.mark.parametrize("L,layers,nseg,M", [(256, 2, 3, 1), (256, 2, 3, 333), (128, 2, 3, 1000), (256, 3, 2, 200),
+                                             (128, 3, 3, 77), (256, 2, 1, 130), (128, 2, 2, 64),
+                                             (256, 2, 3, 40000), (128, 2, 3, 50001)])   # the large ones pre-project
+def test_split3_mlp_vs_fp64(split3, L, layers, nseg, M):
+    from hierarchicalgnn_amd import make_mlp
+    torch.manual_seed(L + 7 * layers + nseg)
+    out_act = "Tanh" if layers == 2 else "GELU"
+    net = make_mlp(nseg * L, 2 * L, L, layers, layer_norm=True, output_activation=out_act,
+                   hidden_activation="GELU").cuda()
+    for p in net.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.2 * torch.randn_like(p))
+    n_tab = max(8, M // 20)
+    table = torch.randn(n_tab, L, device="cuda")
+    i0 = torch.randint(0, n_tab, (M,), device="cuda")
+    i1 = torch.randint(0, n_tab, (M,), device="cuda")
+    direct = torch.randn(M, L, device="cuda")
+    segs = [(table, i0), (table, i1), (direct, None)][3 - nseg:]
+    with torch.no_grad():
+        n0 = split3.stats.get("split3_calls", 0)
+        assert split3.supported(net, segs, direct)
+        out = split3.fused_concat_mlp(net, segs, direct)
+        assert split3.stats.get("split3_calls", 0) == n0 + 1      # the split-bf16 kernel ran, not the fp32 one
+        x = torch.cat([t.double() if i is None else t.double()[i] for t, i in segs], dim=1)
+        ref = net.double()(x) + direct.double()
+    assert out.dtype == torch.float32 and out.shape == ref.shape
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+
+
+def test_split3_config2_ec_in_latent128_within_the_parity_bar(split3):
+    from hierarchicalgnn_amd.models import EC_InteractionGNN
+    z = load_golden("ec_in_L128.npz")
+    model = C._seeded(EC_InteractionGNN, C._cfg("EC-IN"), z)
+    x = torch.from_numpy(z["x"]).cuda()
+    graph = torch.from_numpy(z["edge_index"]).cuda()
+    n0 = split3.stats.get("split3_calls", 0)
+    with torch.inference_mode():
+        scores = model(x, graph)
+    assert split3.stats.get("split3_calls", 0) - n0 == 2 * 14     # every node / edge network of the 14 cells
+    assert np.abs(scores.cpu().numpy() - z["scores"]).max() <= C.TOL
+    assert_parity(scores, z["scores"], C.TOL, "scores")
+
+
+def test_split3_config3_bc_hgnn_gmm_latent256_within_the_parity_bar(split3):
+    from hierarchicalgnn_amd.models import BC_MessagePassing
+    from hierarchicalgnn_amd.utils import process_hparams
+    z = load_golden("bc_hgnn_L256.npz")
+    raw = dict(C._cfg("BC-HGNN-GMM"), latent=256)
+    model = C._seeded(BC_MessagePassing, raw, z).eval()
+    n0 = split3.stats.get("split3_calls", 0)
+    scores = C._bc_stages(model, z, process_hparams(raw), C.TOL, assert_parity)
+    assert split3.stats.get("split3_calls", 0) > n0
+    assert np.abs(scores.cpu().numpy() - z["bipartite_scores"]).max() <= C.TOL
