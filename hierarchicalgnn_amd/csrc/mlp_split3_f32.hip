@@ -480,6 +480,8 @@ extern "C" int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, h
     HGNN_REQUIRE((uintptr_t)out % 16 == 0 && (uintptr_t)a.skip % 16 == 0,
                  "hgnn_mlp_forward_f32_split3: out/skip must be 16-byte aligned");
     const int o = d->width[d->n_layers];
-    if (d->n_layers == 2) return o == 256 ? f3::launch<8, 4, 2, 2>(a, stream) : f3::launch<8, 2, 1, 2>(a, stream);
-    return o == 256 ? f3::launch<8, 4, 2, 3>(a, stream) : f3::launch<8, 2, 1, 3>(a, stream);
+    // latent 128: 4 waves (two 74-KiB workgroups per CU; 8 waves x 1/8 of 256 features left each wave 192 MFMAs per
+    // tile against the tile's fixed costs)
+    if (d->n_layers == 2) return o == 256 ? f3::launch<8, 4, 2, 2>(a, stream) : f3::launch<4, 4, 2, 2>(a, stream);
+    return o == 256 ? f3::launch<8, 4, 2, 3>(a, stream) : f3::launch<4, 4, 2, 3>(a, stream);
 }

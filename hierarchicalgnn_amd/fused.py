@@ -341,7 +341,7 @@ def _split3_weight(weight, kept_cols, panels: bool):
 
 def _try_split3(net, segments, d, keep):
     """re-point a ready fp32 descriptor at split-3 weight streams if the opt-in path supports its shape"""
-    if not _fp32_split3:
+    if not (_fp32_split3 or getattr(net, "_hgnn_split3", False)):
         return False
     layers = _parse(net)
     if layers is None or len(layers) not in (2, 3) or any(ln is None for _, ln, _ in layers):

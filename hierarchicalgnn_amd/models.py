@@ -29,6 +29,16 @@ def _bf16_features(hparams) -> bool:
     return str(hparams.get("feature_dtype", "fp32")).lower() in ("bf16", "bfloat16")
 
 
+def _mark_split3(module, hparams):
+    """hparams["fp32_gemm"] = "split_bf16" (an MI355X-side switch, absent = exact fp32 matrix arithmetic): inference
+    forwards of this module's fp32 MLPs whose shape the kernel supports (node / edge / supernode / superedge networks
+    at latent 128 / 256) evaluate their GEMMs as split-bf16 products (fused.set_fp32_split3 is the process-wide form)"""
+    if str(hparams.get("fp32_gemm", "")).lower() in ("split_bf16", "split3"):
+        for m in module.modules():
+            if isinstance(m, nn.Sequential):
+                m._hgnn_split3 = True
+
+
 def _head_input(t, hparams):
     """score heads in bf16 latent mode: from latent 256 on (hidden >= 512) the head runs as a chain of single-layer
     launches of the bf16 feature-split kernel on the bf16 rows; below that (no 256-wide single-layer instantiation)
@@ -74,6 +84,7 @@ class InteractionGNNBlock(nn.Module):
         self.emb = emb
         self.hparams = hparams
         self._ckpt = bool(hparams.get("checkpointing", True))
+        _mark_split3(self, hparams)
 
     def _encode_nodes(self, x):
         return concat_mlp(self.node_encoder, [(x, None)], bf16_tail=_bf16_features(self.hparams))
@@ -132,6 +143,7 @@ class EC_InteractionGNN(nn.Module):
         self.edge_classifier = make_mlp(2 * hparams["latent"], hparams["hidden"], 1, hparams["output_layers"],
                                         layer_norm=hparams["layernorm"], output_activation=None,
                                         hidden_activation=hparams["hidden_output_activation"])
+        _mark_split3(self, hparams)
 
     def forward(self, x, graph):
         directed_graph = memo(graph, "directed", lambda: torch.cat([graph, graph.flip(0)], dim=1))  # IN.py:122
@@ -182,6 +194,7 @@ class HierarchicalGNNBlock(nn.Module):
         self.register_buffer("score_cut", torch.tensor([float("inf")]))
         self.hparams = hparams
         self._ckpt = bool(hparams.get("checkpointing", True))
+        _mark_split3(self, hparams)
 
     def clustering(self, embeddings, graph, return_count=False):
         """HGNN_GMM.py:184-234 on the GPU (clustering.py): cluster id per hit, -1 = unclustered"""
@@ -255,6 +268,7 @@ class BC_MessagePassing(nn.Module):
                                                hparams["output_layers"], layer_norm=hparams["layernorm"],
                                                output_activation=None,
                                                hidden_activation=hparams["hidden_output_activation"])
+        _mark_split3(self, hparams)
 
     def embed(self, x, graph, restore_order=False):
         """HGNN_GMM.py:328-331: returns (directed_graph, embeddings[N,emb_dim], nodes, edges, order).

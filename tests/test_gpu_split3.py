@@ -63,6 +63,25 @@ def test_split3_config2_ec_in_latent128_within_the_parity_bar(split3):
     assert_parity(scores, z["scores"], C.TOL, "scores")
 
 
+def test_split3_by_hparams_only_marks_that_model():
+    """hparams["fp32_gemm"] = "split_bf16" switches one model's networks; the process-wide default stays exact"""
+    from hierarchicalgnn_amd import fused
+    from hierarchicalgnn_amd.models import EC_InteractionGNN
+    z = load_golden("ec_in_L128.npz")
+    x = torch.from_numpy(z["x"]).cuda()
+    graph = torch.from_numpy(z["edge_index"]).cuda()
+    fast = C._seeded(EC_InteractionGNN, dict(C._cfg("EC-IN"), fp32_gemm="split_bf16"), z)
+    exact = C._seeded(EC_InteractionGNN, C._cfg("EC-IN"), z)
+    with torch.inference_mode():
+        n0 = fused.stats.get("split3_calls", 0)
+        s_exact = exact(x, graph)
+        assert fused.stats.get("split3_calls", 0) == n0
+        s_fast = fast(x, graph)
+        assert fused.stats.get("split3_calls", 0) == n0 + 2 * 14
+    assert np.abs(s_fast.cpu().numpy() - z["scores"]).max() <= C.TOL
+    assert float((s_fast - s_exact).abs().max()) > 0.0          # (they are different arithmetic)
+
+
 def test_split3_config3_bc_hgnn_gmm_latent256_within_the_parity_bar(split3):
     from hierarchicalgnn_amd.models import BC_MessagePassing
     from hierarchicalgnn_amd.utils import process_hparams
