@@ -428,6 +428,7 @@ extern "C" int hgnn_mlp_supported_f32_split3(const hgnn_mlp_desc* d) {
     if (d->M < 0 || d->M > 0x7fffffffLL) return 0;
     const int h = d->width[1], o = d->width[n];
     if (n == 3 && d->width[2] != h) return 0;
+    if (n == 2 && o == h) return (h == 256 || h == 512) ? 1 : 0;   // the two hidden layers of a score head
     if (h != 2 * o) return 0;
     return (o == 128 || o == 256) ? 1 : 0;
 }
@@ -436,8 +437,8 @@ extern "C" int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, h
     hipStream_t stream = (hipStream_t)stream_;
     HGNN_REQUIRE(d != nullptr && out != nullptr, "hgnn_mlp_forward_f32_split3: NULL argument");
     if (!hgnn_mlp_supported_f32_split3(d)) {
-        set_error("hgnn_mlp_forward_f32_split3: unsupported shape (K -> 2L (-> 2L) -> L, L in {128, 256}, LayerNorm on "
-                  "every layer, every segment a multiple of 128 wide, no save_pre)");
+        set_error("hgnn_mlp_forward_f32_split3: unsupported shape (K -> 2L (-> 2L) -> L, L in {128, 256}, or K -> H -> H, "
+                  "H in {256, 512}; LayerNorm on every layer, every segment a multiple of 128 wide, no save_pre)");
         return HGNN_ERR_UNSUPPORTED;
     }
     if (d->M == 0) return HGNN_OK;
@@ -480,6 +481,8 @@ extern "C" int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, h
     HGNN_REQUIRE((uintptr_t)out % 16 == 0 && (uintptr_t)a.skip % 16 == 0,
                  "hgnn_mlp_forward_f32_split3: out/skip must be 16-byte aligned");
     const int o = d->width[d->n_layers];
+    if (d->n_layers == 2 && o == d->width[1])
+        return o == 512 ? f3::launch<8, 4, 4, 2>(a, stream) : f3::launch<4, 4, 4, 2>(a, stream);
     // latent 128: 4 waves (two 74-KiB workgroups per CU; 8 waves x 1/8 of 256 features left each wave 192 MFMAs per
     // tile against the tile's fixed costs)
     if (d->n_layers == 2) return o == 256 ? f3::launch<8, 4, 2, 2>(a, stream) : f3::launch<4, 4, 2, 2>(a, stream);

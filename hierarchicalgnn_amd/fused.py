@@ -339,18 +339,26 @@ def _split3_weight(weight, kept_cols, panels: bool):
     return Wv
 
 
-def _try_split3(net, segments, d, keep):
-    """re-point a ready fp32 descriptor at split-3 weight streams if the opt-in path supports its shape"""
-    if not (_fp32_split3 or getattr(net, "_hgnn_split3", False)):
+def _split3_applies(net, segments) -> bool:
+    """the opt-in split-bf16 path is switched on for this network and hgnn_mlp_forward_f32_split3 has its shape"""
+    if not (_fp32_split3 or getattr(net, "_hgnn_split3", False)) or torch.is_grad_enabled() and any(
+            p.requires_grad for p in net.parameters()):
         return False
     layers = _parse(net)
     if layers is None or len(layers) not in (2, 3) or any(ln is None for _, ln, _ in layers):
         return False
-    if int(d.w0_cols) != 0 or int(d.w_last_rows) != 0 or any(int(d.seg_width[i]) % 128 for i in range(int(d.n_seg))):
+    if any(t.dtype != torch.float32 or int(t.shape[1]) % 128 for t, _ in segments):
         return False
     o = layers[-1][0].out_features
-    if o not in (128, 256) or any(lin.out_features != 2 * o for lin, _, _ in layers[:-1]):
+    head_body = len(layers) == 2 and layers[0][0].out_features == o and o in (256, 512)
+    return head_body or (o in (128, 256) and all(lin.out_features == 2 * o for lin, _, _ in layers[:-1]))
+
+
+def _try_split3(net, segments, d, keep):
+    """re-point a ready fp32 descriptor at split-3 weight streams if the opt-in path supports its shape"""
+    if not _split3_applies(net, segments) or int(d.w0_cols) != 0 or int(d.w_last_rows) != 0:
         return False
+    layers = _parse(net)
     kept = None
     if int(d.n_pre):
         # the columns of the segments that stayed in the kernel's K loop, in order
@@ -576,8 +584,29 @@ def supported(net, segments, skip, allow_chain: bool = True) -> bool:
     return allow_chain and _chain_supported(net, segments, skip)
 
 
+def _split3_head(net, segments, skip) -> bool:
+    """score heads (K -> H -> H -> w, plain last layer; IN.py:107-115, HGNN_GMM.py:313-321) under the opt-in
+    split-bf16 mode: the two LayerNorm'ed hidden layers run on hgnn_mlp_forward_f32_split3, the plain last Linear is
+    a trailing matrix-vector product over the hidden rows"""
+    if not (_fp32_split3 or getattr(net, "_hgnn_split3", False)) or skip is not None:
+        return False
+    layers = _parse(net)
+    if layers is None or len(layers) != 3 or layers[2][1] is not None or layers[0][1] is None or layers[1][1] is None:
+        return False
+    h = layers[0][0].out_features
+    if h not in (256, 512) or layers[1][0].out_features != h or len(list(net)) != 7:
+        return False
+    return all(t.dtype == torch.float32 and int(t.shape[1]) % 128 == 0 for t, _ in segments)
+
+
 def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
     bf16 = _is_bf16(segments)
+    if not bf16 and _split3_head(net, segments, skip):
+        mods = list(net)
+        body = nn.Sequential(*mods[:6])
+        body._hgnn_split3 = True
+        hid = fused_concat_mlp(body, segments, None)
+        return torch.nn.functional.linear(hid, mods[6].weight, mods[6].bias)
     if len(_parse(net) or []) > 1:
         if bf16:
             sp = _wants_split(net, segments)
@@ -586,7 +615,8 @@ def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
                                                    _lib.load().hgnn_mlp_supported_bf16)(ctypes.byref(whole[0])))
         else:
             whole = _descriptor(net, segments, skip, dry=True)
-            whole_ok = whole is not None and bool(_lib.load().hgnn_mlp_supported(ctypes.byref(whole[0])))
+            whole_ok = whole is not None and (bool(_lib.load().hgnn_mlp_supported(ctypes.byref(whole[0])))
+                                              or _split3_applies(net, segments))
         if not whole_ok and _chain_supported(net, segments, skip):
             # one launch per layer; the hidden rows make one trip through HBM (fp32 at latent 512)
             chain = _layer_chain(net)

@@ -49,6 +49,23 @@ def test_split3_mlp_vs_fp64(split3, L, layers, nseg, M):
     assert float((out.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("H,M", [(256, 1000), (512, 333)])
+def test_split3_score_head_vs_fp64(split3, H, M):
+    """K -> H -> H -> 1 with a plain last layer: hidden layers on the split-bf16 kernel, last Linear trailing"""
+    from hierarchicalgnn_amd import make_mlp
+    torch.manual_seed(H)
+    L = H // 2
+    net = make_mlp(2 * L, H, 1, 3, layer_norm=True, output_activation=None, hidden_activation="GELU").cuda()
+    a, b = torch.randn(M, L, device="cuda"), torch.randn(M, L, device="cuda")
+    with torch.no_grad():
+        n0 = split3.stats.get("split3_calls", 0)
+        out = split3.fused_concat_mlp(net, [(a, None), (b, None)], None)
+        assert split3.stats.get("split3_calls", 0) == n0 + 1
+        ref = net.double()(torch.cat([a, b], dim=1).double())
+    assert out.shape == (M, 1)
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+
+
 def test_split3_config2_ec_in_latent128_within_the_parity_bar(split3):
     from hierarchicalgnn_amd.models import EC_InteractionGNN
     z = load_golden("ec_in_L128.npz")
@@ -58,7 +75,7 @@ def test_split3_config2_ec_in_latent128_within_the_parity_bar(split3):
     n0 = split3.stats.get("split3_calls", 0)
     with torch.inference_mode():
         scores = model(x, graph)
-    assert split3.stats.get("split3_calls", 0) - n0 == 2 * 14     # every node / edge network of the 14 cells
+    assert split3.stats.get("split3_calls", 0) - n0 == 2 * 14 + 1  # every node / edge network of the 14 cells + the head
     assert np.abs(scores.cpu().numpy() - z["scores"]).max() <= C.TOL
     assert_parity(scores, z["scores"], C.TOL, "scores")
 
@@ -77,7 +94,7 @@ def test_split3_by_hparams_only_marks_that_model():
         s_exact = exact(x, graph)
         assert fused.stats.get("split3_calls", 0) == n0
         s_fast = fast(x, graph)
-        assert fused.stats.get("split3_calls", 0) == n0 + 2 * 14
+        assert fused.stats.get("split3_calls", 0) == n0 + 2 * 14 + 1
     assert np.abs(s_fast.cpu().numpy() - z["scores"]).max() <= C.TOL
     assert float((s_fast - s_exact).abs().max()) > 0.0          # (they are different arithmetic)
 
