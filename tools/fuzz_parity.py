@@ -94,6 +94,19 @@ for case in range(n_cases):
         out = mlp.concat_mlp(net, segs, skip=direct)
         ref = net(torch.cat([tab[i0], tab[i1], direct], dim=1)) + direct
     note("fused_mlp_f32", rel(out, ref), 1e-4, (L, layers, Mm, n_tab))
+    if L >= 128:
+        # opt-in split-bf16 evaluation of the same fp32 MLP (hgnn_mlp_forward_f32_split3): against fp64
+        fused.set_fp32_split3(True)
+        try:
+            n_s3 = fused.stats.get("split3_calls", 0)
+            with torch.no_grad():
+                o3 = mlp.concat_mlp(net, segs, skip=direct)
+                ref64 = net.double()(torch.cat([tab[i0], tab[i1], direct], dim=1).double()) + direct.double()
+                net.float()
+            assert fused.stats.get("split3_calls", 0) == n_s3 + 1
+        finally:
+            fused.set_fp32_split3(False)
+        note("fused_mlp_f32_split3_vs_fp64", rel(o3, ref64), 3e-5, (L, layers, Mm, n_tab))
     t1, d1 = tab.clone().requires_grad_(True), direct.clone().requires_grad_(True)
     r = torch.randn(Mm, L, generator=g).cuda()
     n0 = fused.stats["fused_train_calls"]
