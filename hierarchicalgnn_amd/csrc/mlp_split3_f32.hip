@@ -205,7 +205,7 @@ __device__ __forceinline__ void gemm3s(f32x4 (&acc)[NT][NJ], const u16x8* __rest
 // rows leave room for ONE workgroup per CU, whose waves are phase-locked by the barriers: more of them hide more
 // latency); NTH / NTO: 16-feature tiles per wave of the hidden / output layers; NL = 2 or 3 layers
 template <int NW, int NTH, int NTO, int NL>
-__global__ __launch_bounds__(NW * 64, 1) void k_mlp_f32_split3(const Args a) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = NW * 64;
     constexpr int H = NTH * NW * 16;
@@ -217,176 +217,234 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mlp_f32_split3(const Args a) {
     constexpr int NC = H / 32;                 // k-chunks of a hidden layer (per plane)
     float* red = (float*)(smem + REGION);                 // [NW][TE][sum, sumsq]
     int32_t* pidx = (int32_t*)(red + NW * TE * 2);        // [2][TE]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ei = lane & 15;
-    const int g = lane >> 4;
-    const long long e0 = (long long)blockIdx.x * TE;
-
-    // ---- input panels: 32 threads move one row's 128 fp32 (16 bytes each), 16 rows per pass
-    constexpr int LPR = PK * 4 / 16;   // 32
-    constexpr int RPP = NTHR / LPR;    // 16
-    constexpr int NP = TE / RPP;       // 4
-    const int prow = tid / LPR;
-    const int pcol = tid % LPR;
-    const float* px[NP];
-    int r1[NP], r2[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        long long e = e0 + i * RPP + prow;
-        if (e >= a.M) e = a.M - 1;
-        long long r0 = a.seg_index[0] != nullptr ? (long long)a.seg_index[0][e] : e;
-        if (r0 < 0) r0 = 0;
-        px[i] = a.seg_table[0] + (size_t)r0 * (size_t)a.seg_width[0] + pcol * 4;
-        r1[i] = a.n_seg > 1 ? (a.seg_index[1] != nullptr ? a.seg_index[1][e] : (int)e) : 0;
-        r2[i] = a.n_seg > 2 ? (a.seg_index[2] != nullptr ? a.seg_index[2][e] : (int)e) : 0;
-        if (r1[i] < 0) r1[i] = 0;
-        if (r2[i] < 0) r2[i] = 0;
-    }
+    // Everything derived from the lane id is tile-invariant; in the persistent loop hipcc hoists all of it out of the
+    // loop and spills it (136-257 registers in the first persistent build).  refresh() makes the thread id opaque at
+    // the top of every tile, so the address arithmetic is redone where it is used (mlp_rows128_bf16.hip, same cure).
+    int lane, ei, g, prow, pcol;
+    constexpr int LPR = PK * 4 / 16;   // 32 threads move one row's 128 fp32 (16 bytes each)
+    auto refresh = [&]() {
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        ei = lane & 15;
+        g = lane >> 4;
+        prow = tid / LPR;
+        pcol = tid % LPR;
+    };
+    refresh();
+    // gather rows of a tile, staged in LDS one tile ahead: [parity][3 segments + 2 pre-projected][TE]
+    int32_t* tix = pidx + 2 * TE;
+    const long long n_tiles = (a.M + TE - 1) / TE;
+    constexpr int NIX = (5 * TE + NTHR - 1) / NTHR;   // table entries per thread (1 with 8 waves, 2 with 4)
+    auto fetch_index = [&](long long tile, int k) {   // entry tid + k NTHR (< 5 TE) of the tile's table
+        int r = 0;
+        const int slot = tid + k * NTHR;
+        if (slot < 5 * TE) {
+            const int which = slot / TE;
+            long long e = tile * TE + (slot % TE);
+            if (e >= a.M) e = a.M - 1;
+            r = (int)e;
+            const int32_t* ix = which < 3 ? (which < a.n_seg ? a.seg_index[which] : nullptr)
+                                          : (which - 3 < a.n_pre ? a.pre_index[which - 3] : nullptr);
+            if (ix != nullptr) r = ix[e];
+            if (which >= 3 && which - 3 >= a.n_pre) r = 0;
+        }
+        return r < 0 ? 0 : r;
+    };
+    // ---- input panels: 16 rows per pass with 8 waves
+    constexpr int RPP = NTHR / LPR;
+    constexpr int NP = TE / RPP;
     const int np = a.K1 / PK;
     const int p1 = a.seg_width[0] / PK;
     const int p2 = p1 + (a.n_seg > 1 ? a.seg_width[1] / PK : np);
-    f32x4 st[NP];
-    int pl = 0;
-    auto load_panel = [&]() {
+    constexpr int PPR = PHB / 16;
+    constexpr int NPI = 16 * PHB / 1024;
+    constexpr int IPW = NPI / NW;
+    static_assert(NPI % NW == 0, "P pass does not split over the waves");
+    const int npass = a.n_pre * NJ;
+    // pre-projected gathered segments (fp32 rows): whole rows by LDS-DMA through a ring of four 16-row buffers
+    auto pissue = [&](int p, const int32_t* ti) {
+        const int sgm = p / NJ, j = p % NJ;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            st[i] = *(const f32x4*)px[i];
-            px[i] += PK;
-        }
-        ++pl;
-        if (pl == p1) {
-#pragma unroll
-            for (int i = 0; i < NP; ++i) px[i] = a.seg_table[1] + (size_t)r1[i] * (size_t)a.seg_width[1] + pcol * 4;
-        }
-        if (pl == p2) {
-#pragma unroll
-            for (int i = 0; i < NP; ++i) px[i] = a.seg_table[2] + (size_t)r2[i] * (size_t)a.seg_width[2] + pcol * 4;
-        }
-    };
-    auto store_panel = [&](int buf) {   // buffers 2 buf (hi) and 2 buf + 1 (mid)
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            u16x4 h, m;
-            split4(st[i], h, m);
-            char* dst = smem + (2 * buf) * PANEL + (i * RPP + prow) * PRS + pcol * 8;
-            *(u16x4*)dst = h;
-            *(u16x4*)(dst + PANEL) = m;
+        for (int i = 0; i < IPW; ++i) {
+            const int k = wave + i * NW;
+            const int gp = k * 64 + lane;
+            const int row = gp / PPR, pc = gp % PPR;
+            const int r = ti[(3 + sgm) * TE + 16 * j + row];
+            const char* src = (const char*)(a.pre_table[sgm] + (size_t)r * H) + (((pc & ~15) | ((pc ^ row) & 15)) << 4);
+            dma_piece(src, lds_addr_of((float*)(smem + (p & 3) * 16 * PHB)) + (unsigned)k * 1024u);
         }
     };
 
-    // ---------------- layer 1
-    f32x4 acc1[NTH][NJ];
-    init_bias<NTH>(acc1, a.b[0] + wave * NTH * 16 + 4 * g);
-    // the first input panel is requested BEFORE the pre-projected rows: it is older in the in-order vector-memory
-    // queue, so the counted waits of the DMA ring below stay exact, and its latency hides under the P phase
-    const int vtotal = 2 * (a.K1 / 32);
-    const u16x8* wp = (const u16x8*)a.W[0] + (size_t)(wave * NTH) * 64 + lane;
-    load_panel();
-    if (a.n_pre > 0) {
-        // pre-projected gathered segments (fp32 rows): whole rows by LDS-DMA through a ring of four 16-row buffers,
-        // added in the accumulator layout from LDS (see mlp_split_bf16.hip)
-        constexpr int PPR = PHB / 16;
-        constexpr int NPI = 16 * PHB / 1024;
-        constexpr int IPW = NPI / NW;
-        static_assert(NPI % NW == 0, "P pass does not split over the waves");
-        for (int i = tid; i < 2 * TE; i += NTHR) {
-            const int sgm = i / TE;
-            long long e = e0 + (i % TE);
-            if (e >= a.M) e = a.M - 1;
-            const int r = sgm < a.n_pre ? a.pre_index[sgm][e] : 0;
-            pidx[i] = r < 0 ? 0 : r;
-        }
-        __syncthreads();
-        const int npass = a.n_pre * NJ;
-        auto pissue = [&](int p) {
-            const int sgm = p / NJ, j = p % NJ;
+    long long tile = blockIdx.x;
+    if (tile >= n_tiles) return;
 #pragma unroll
-            for (int i = 0; i < IPW; ++i) {
-                const int k = wave + i * NW;
-                const int gp = k * 64 + lane;
-                const int row = gp / PPR, pc = gp % PPR;
-                const int r = pidx[sgm * TE + 16 * j + row];
-                const char* src = (const char*)(a.pre_table[sgm] + (size_t)r * H) + (((pc & ~15) | ((pc ^ row) & 15)) << 4);
-                dma_piece(src, lds_addr_of((float*)(smem + (p & 3) * 16 * PHB)) + (unsigned)k * 1024u);
+    for (int k = 0; k < NIX; ++k) {
+        const int r = fetch_index(tile, k);
+        if (tid + k * NTHR < 5 * TE) tix[tid + k * NTHR] = r;
+    }
+    __syncthreads();
+    // Persistent workgroups: the hidden planes leave ONE workgroup per CU at latent 256, so nothing overlaps a tile's
+    // start-up chain (gather indices -> projected rows -> first panel) unless the tile before requests it: the next
+    // tile's indices are fetched under the output GEMM, its first three P passes under the output epilogue.
+    for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+        const int32_t* ti = tix + (it & 1) * 5 * TE;
+        int32_t* ti_next = tix + ((it + 1) & 1) * 5 * TE;
+        const bool has_next = tile + gridDim.x < n_tiles;
+        const long long e0 = tile * TE;
+        refresh();
+        const float* px[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            px[i] = a.seg_table[0] + (size_t)ti[i * RPP + prow] * (size_t)a.seg_width[0] + pcol * 4;
+        f32x4 st[NP];
+        int pl = 0;
+        auto load_panel = [&]() {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                st[i] = *(const f32x4*)px[i];
+                px[i] += PK;
+            }
+            ++pl;
+            if (pl == p1) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    px[i] = a.seg_table[1] + (size_t)ti[TE + i * RPP + prow] * (size_t)a.seg_width[1] + pcol * 4;
+            }
+            if (pl == p2) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    px[i] = a.seg_table[2] + (size_t)ti[2 * TE + i * RPP + prow] * (size_t)a.seg_width[2] + pcol * 4;
             }
         };
-        pissue(0);
-        if (npass > 1) pissue(1);
-        if (npass > 2) pissue(2);
+        auto store_panel = [&](int buf) {   // buffers 2 buf (hi) and 2 buf + 1 (mid)
 #pragma unroll
-        for (int p = 0; p < 2 * NJ; ++p) {
-            if (p < npass) {
-                if (p + 2 < npass) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
-                else if (p + 1 < npass) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                const char* buf = smem + (p & 3) * 16 * PHB + ei * PHB;
-#pragma unroll
-                for (int t = 0; t < NTH; ++t) {
-                    const int q = 4 * (wave * NTH + t) + g;
-                    acc1[t][p % NJ] += *(const f32x4*)(buf + (((q & ~15) | ((q ^ ei) & 15)) << 4));
-                }
-                if (p + 3 < npass) pissue(p + 3);
+            for (int i = 0; i < NP; ++i) {
+                u16x4 h, m;
+                split4(st[i], h, m);
+                char* dst = smem + (2 * buf) * PANEL + (i * RPP + prow) * PRS + pcol * 8;
+                *(u16x4*)dst = h;
+                *(u16x4*)(dst + PANEL) = m;
             }
-        }
-        __syncthreads();
-    }
-    {
-        store_panel(0);
-        __syncthreads();
-        const char* blane = smem + ei * PRS + (g << 4);
-        for (int p = 0; p < np; ++p) {
-            const bool more = p + 1 < np;
-            if (more) load_panel();
-            const char* bh = blane + (2 * (p & 1)) * PANEL;
-            gemm3s<NTH, PRS, NW>(acc1, wp, 2 * p * CPP, vtotal, bh, bh + PANEL, CPP);
-            if (more) store_panel((p + 1) & 1);
+        };
+
+        // ---------------- layer 1
+        f32x4 acc1[NTH][NJ];
+        init_bias<NTH>(acc1, a.b[0] + wave * NTH * 16 + 4 * g);
+        // the first input panel is requested BEFORE the (first tile's) pre-projected rows: it is older in the in-order
+        // vector-memory queue, so the counted waits of the DMA ring below stay conservative
+        const int vtotal = 2 * (a.K1 / 32);
+        const u16x8* wp = (const u16x8*)a.W[0] + (size_t)(wave * NTH) * 64 + lane;
+        load_panel();
+        if (npass > 0) {
+            if (it == 0) {   // later tiles: requested under the previous tile's output epilogue
+                pissue(0, ti);
+                if (npass > 1) pissue(1, ti);
+                if (npass > 2) pissue(2, ti);
+            }
+#pragma unroll
+            for (int p = 0; p < 2 * NJ; ++p) {
+                if (p < npass) {
+                    // at most the two younger passes' DMAs may still be out (everything else this wave issued since --
+                    // stores, index and panel loads -- is younger still: the count is conservative)
+                    if (p + 2 < npass) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+                    else if (p + 1 < npass) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    const char* buf = smem + (p & 3) * 16 * PHB + ei * PHB;
+#pragma unroll
+                    for (int t = 0; t < NTH; ++t) {
+                        const int q = 4 * (wave * NTH + t) + g;
+                        acc1[t][p % NJ] += *(const f32x4*)(buf + (((q & ~15) | ((q ^ ei) & 15)) << 4));
+                    }
+                    if (p + 3 < npass) pissue(p + 3, ti);
+                }
+            }
             __syncthreads();
         }
-    }
-    layernorm_act<NTH, NW>(acc1, a.lnw[0] + wave * NTH * 16 + 4 * g, a.lnb[0] + wave * NTH * 16 + 4 * g, a.act[0], a.eps, red,
-                       wave, ei, g);
-    // (the barrier inside layernorm_act also means: every wave is done reading the panels)
-    write_hidden2<NTH, HRS, PLB>(acc1, smem, wave, ei, g);
-    __syncthreads();
-    const char* hlane = smem + ei * HRS + (g << 4);
-    if constexpr (NL == 3) {
-        // ---------------- middle layer (same width), hidden planes rewritten in place
-        init_bias<NTH>(acc1, a.b[1] + wave * NTH * 16 + 4 * g);
         {
-            const u16x8* wp1 = (const u16x8*)a.W[1] + (size_t)(wave * NTH) * 64 + lane;
-            gemm3s<NTH, HRS, NW>(acc1, wp1, 0, 2 * NC, hlane, hlane + PLB, NC);
+            store_panel(0);
+            __syncthreads();
+            const char* blane = smem + ei * PRS + (g << 4);
+            for (int p = 0; p < np; ++p) {
+                const bool more = p + 1 < np;
+                if (more) load_panel();
+                const char* bh = blane + (2 * (p & 1)) * PANEL;
+                gemm3s<NTH, PRS, NW>(acc1, wp, 2 * p * CPP, vtotal, bh, bh + PANEL, CPP);
+                if (more) store_panel((p + 1) & 1);
+                __syncthreads();
+            }
         }
-        layernorm_act<NTH, NW>(acc1, a.lnw[1] + wave * NTH * 16 + 4 * g, a.lnb[1] + wave * NTH * 16 + 4 * g, a.act[1], a.eps,
-                           red, wave, ei, g);
-        write_hidden2<NTH, HRS, PLB>(acc1, smem, wave, ei, g);   // (barrier inside layernorm_act: all reads done)
+        layernorm_act<NTH, NW>(acc1, a.lnw[0] + wave * NTH * 16 + 4 * g, a.lnb[0] + wave * NTH * 16 + 4 * g, a.act[0], a.eps,
+                               red, wave, ei, g);
+        // (the barrier inside layernorm_act also means: every wave is done reading the panels)
+        write_hidden2<NTH, HRS, PLB>(acc1, smem, wave, ei, g);
         __syncthreads();
-    }
-    // ---------------- output layer
-    constexpr int LO = NL - 1;
-    f32x4 acc2[NTO][NJ];
-    init_bias<NTO>(acc2, a.b[LO] + wave * NTO * 16 + 4 * g);
-    {
-        const u16x8* wpo = (const u16x8*)a.W[LO] + (size_t)(wave * NTO) * 64 + lane;
-        gemm3s<NTO, HRS, NW>(acc2, wpo, 0, 2 * NC, hlane, hlane + PLB, NC);
-    }
-    layernorm_act<NTO, NW>(acc2, a.lnw[LO] + wave * NTO * 16 + 4 * g, a.lnb[LO] + wave * NTO * 16 + 4 * g, a.act[LO], a.eps,
-                       red, wave, ei, g);
+        const char* hlane = smem + ei * HRS + (g << 4);
+        if constexpr (NL == 3) {
+            // ---------------- middle layer (same width), hidden planes rewritten in place
+            init_bias<NTH>(acc1, a.b[1] + wave * NTH * 16 + 4 * g);
+            {
+                const u16x8* wp1 = (const u16x8*)a.W[1] + (size_t)(wave * NTH) * 64 + lane;
+                gemm3s<NTH, HRS, NW>(acc1, wp1, 0, 2 * NC, hlane, hlane + PLB, NC);
+            }
+            layernorm_act<NTH, NW>(acc1, a.lnw[1] + wave * NTH * 16 + 4 * g, a.lnb[1] + wave * NTH * 16 + 4 * g, a.act[1],
+                                   a.eps, red, wave, ei, g);
+            write_hidden2<NTH, HRS, PLB>(acc1, smem, wave, ei, g);   // (barrier inside layernorm_act: all reads done)
+            __syncthreads();
+        }
+        // ---------------- output layer
+        refresh();
+        constexpr int LO = NL - 1;
+        f32x4 acc2[NTO][NJ];
+        init_bias<NTO>(acc2, a.b[LO] + wave * NTO * 16 + 4 * g);
+        int r_next[NIX];   // fly under the output GEMM
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const long long e = e0 + j * 16 + ei;
-        if (e >= a.M) continue;
-        const size_t off = (size_t)e * O + (size_t)(wave * NTO * 16 + 4 * g);
+        for (int k = 0; k < NIX; ++k) r_next[k] = has_next ? fetch_index(tile + gridDim.x, k) : 0;
+        {
+            const u16x8* wpo = (const u16x8*)a.W[LO] + (size_t)(wave * NTO) * 64 + lane;
+            gemm3s<NTO, HRS, NW>(acc2, wpo, 0, 2 * NC, hlane, hlane + PLB, NC);
+        }
 #pragma unroll
-        for (int t = 0; t < NTO; ++t) {
-            f32x4 v = acc2[t][j];
-            if (a.skip != nullptr) v += *(const f32x4*)(a.skip + off + t * 16);
-            *(f32x4*)(a.out + off + t * 16) = v;
+        for (int k = 0; k < NIX; ++k)
+            if (has_next && tid + k * NTHR < 5 * TE) ti_next[tid + k * NTHR] = r_next[k];
+        // skip rows BEFORE the next tile's DMAs: queued behind them they would wait for the projected rows
+        f32x4 sk[NTO][NJ];
+        size_t off[NJ];
+        bool valid[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const long long e = e0 + j * 16 + ei;
+            valid[j] = e < a.M;
+            off[j] = (size_t)(valid[j] ? e : a.M - 1) * O + (size_t)(wave * NTO * 16 + 4 * g);
+            if (a.skip != nullptr) {
+#pragma unroll
+                for (int t = 0; t < NTO; ++t) sk[t][j] = *(const f32x4*)(a.skip + off[j] + t * 16);
+            }
+        }
+        layernorm_act<NTO, NW>(acc2, a.lnw[LO] + wave * NTO * 16 + 4 * g, a.lnb[LO] + wave * NTO * 16 + 4 * g, a.act[LO],
+                               a.eps, red, wave, ei, g);
+        // (the barrier inside: every wave is past the hidden planes, the next tile's indices are visible)
+        if (has_next && npass > 0) {
+            pissue(0, ti_next);
+            if (npass > 1) pissue(1, ti_next);
+            if (npass > 2) pissue(2, ti_next);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (!valid[j]) continue;
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) {
+                f32x4 v = acc2[t][j];
+                if (a.skip != nullptr) v += sk[t][j];
+                *(f32x4*)(a.out + off[j] + t * 16) = v;
+            }
         }
     }
 }
+
+static int g_cus = 0;
 
 template <int NW, int NTH, int NTO, int NL>
 static int launch(const Args& a, hipStream_t s) {
@@ -394,8 +452,17 @@ static int launch(const Args& a, hipStream_t s) {
     constexpr int H = NTH * NW * 16;
     constexpr int HRS = H * 2 + 16;
     constexpr int REGION = cmax(cmax(2 * TE * HRS, 4 * PANEL), 4 * 16 * H * 4);
-    const size_t lds_bytes = (size_t)REGION + NW * TE * 2 * sizeof(float) + 2 * TE * sizeof(int32_t);
-    const unsigned grid = (unsigned)ceil_div(a.M, TE);
+    const size_t lds_bytes = (size_t)REGION + NW * TE * 2 * sizeof(float) + 2 * TE * sizeof(int32_t) +
+                             2 * 5 * TE * sizeof(int32_t);
+    if (g_cus == 0) {
+        int dev = 0;
+        HGNN_CHECK_HIP(hipGetDevice(&dev));
+        HGNN_CHECK_HIP(hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (g_cus <= 0) g_cus = 256;
+    }
+    const long long n_tiles = ceil_div(a.M, TE);
+    const long long resident = (long long)g_cus * (lds_bytes <= 80 * 1024 ? 2 : 1);   // persistent workgroups
+    const unsigned grid = (unsigned)(n_tiles < resident ? n_tiles : resident);
     auto kern = k_mlp_f32_split3<NW, NTH, NTO, NL>;
     HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     kern<<<grid, NTHR, lds_bytes, s>>>(a);
