@@ -43,6 +43,7 @@ struct Args {
     const float* pre_table[2];
     const int32_t* pre_index[2];
     int n_pre;
+    float* save_pre[3];   // optional fp32 [M, width_l] dumps of each layer's pre-LayerNorm output (training forward)
 };
 
 constexpr int NJ = 4;
@@ -130,6 +131,21 @@ __device__ __forceinline__ void init_bias(f32x4 (&acc)[NT][NJ], const float* __r
         const f32x4 bv = *(const f32x4*)(b + t * 16);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[t][j] = bv;
+    }
+}
+
+// training: this wave's slice of a layer's pre-LayerNorm rows -> fp32 [M, NOUT]
+template <int NT, int NOUT>
+__device__ __forceinline__ void dump_pre(const f32x4 (&acc)[NT][NJ], float* base, long long M, long long e0, int wave,
+                                         int ei, int g) {
+    if (base == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long e = e0 + j * 16 + ei;
+        if (e >= M) continue;
+        float* p = base + (size_t)e * NOUT + (size_t)(wave * NT * 16 + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *(f32x4*)(p + t * 16) = acc[t][j];
     }
 }
 
@@ -376,6 +392,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
                 __syncthreads();
             }
         }
+        dump_pre<NTH, H>(acc1, a.save_pre[0], a.M, e0, wave, ei, g);
         layernorm_act<NTH, NW>(acc1, a.lnw[0] + wave * NTH * 16 + 4 * g, a.lnb[0] + wave * NTH * 16 + 4 * g, a.act[0], a.eps,
                                red, wave, ei, g);
         // (the barrier inside layernorm_act also means: every wave is done reading the panels)
@@ -389,6 +406,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
                 const u16x8* wp1 = (const u16x8*)a.W[1] + (size_t)(wave * NTH) * 64 + lane;
                 gemm3s<NTH, HRS, NW>(acc1, wp1, 0, 2 * NC, hlane, hlane + PLB, NC);
             }
+            dump_pre<NTH, H>(acc1, a.save_pre[1], a.M, e0, wave, ei, g);
             layernorm_act<NTH, NW>(acc1, a.lnw[1] + wave * NTH * 16 + 4 * g, a.lnb[1] + wave * NTH * 16 + 4 * g, a.act[1],
                                    a.eps, red, wave, ei, g);
             write_hidden2<NTH, HRS, PLB>(acc1, smem, wave, ei, g);   // (barrier inside layernorm_act: all reads done)
@@ -409,6 +427,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
 #pragma unroll
         for (int k = 0; k < NIX; ++k)
             if (has_next && tid + k * NTHR < 5 * TE) ti_next[tid + k * NTHR] = r_next[k];
+        dump_pre<NTO, O>(acc2, a.save_pre[LO], a.M, e0, wave, ei, g);
         // skip rows BEFORE the next tile's DMAs: queued behind them they would wait for the projected rows
         f32x4 sk[NTO][NJ];
         size_t off[NJ];
@@ -487,8 +506,6 @@ extern "C" int hgnn_mlp_supported_f32_split3(const hgnn_mlp_desc* d) {
     const int n = d->n_layers;
     for (int l = 0; l < n; ++l)
         if (d->W[l] == nullptr || d->b[l] == nullptr || d->ln_w[l] == nullptr || d->ln_b[l] == nullptr) return 0;
-    for (int l = 0; l < 3; ++l)
-        if (d->save_pre[l] != nullptr) return 0;   // inference forward only
     if (d->n_pre < 0 || d->n_pre > 2) return 0;
     for (int s = 0; s < d->n_pre; ++s)
         if (d->pre_table[s] == nullptr || d->pre_index[s] == nullptr) return 0;
@@ -505,7 +522,7 @@ extern "C" int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, h
     HGNN_REQUIRE(d != nullptr && out != nullptr, "hgnn_mlp_forward_f32_split3: NULL argument");
     if (!hgnn_mlp_supported_f32_split3(d)) {
         set_error("hgnn_mlp_forward_f32_split3: unsupported shape (K -> 2L (-> 2L) -> L, L in {128, 256}, or K -> H -> H, "
-                  "H in {256, 512}; LayerNorm on every layer, every segment a multiple of 128 wide, no save_pre)");
+                  "H in {256, 512}; LayerNorm on every layer, every segment a multiple of 128 wide, save_pre optional)");
         return HGNN_ERR_UNSUPPORTED;
     }
     if (d->M == 0) return HGNN_OK;
@@ -529,10 +546,12 @@ extern "C" int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, h
         a.lnw[l] = on ? d->ln_w[l] : nullptr;
         a.lnb[l] = on ? d->ln_b[l] : nullptr;
         a.act[l] = on ? d->act[l] : 0;
+        a.save_pre[l] = on ? d->save_pre[l] : nullptr;
         if (on) {
             HGNN_REQUIRE((uintptr_t)a.W[l] % 16 == 0 && (uintptr_t)a.b[l] % 16 == 0 &&
-                             (uintptr_t)a.lnw[l] % 16 == 0 && (uintptr_t)a.lnb[l] % 16 == 0,
-                         "hgnn_mlp_forward_f32_split3: layer %d parameters must be 16-byte aligned", l);
+                             (uintptr_t)a.lnw[l] % 16 == 0 && (uintptr_t)a.lnb[l] % 16 == 0 &&
+                             (uintptr_t)a.save_pre[l] % 16 == 0,
+                         "hgnn_mlp_forward_f32_split3: layer %d parameters / save_pre must be 16-byte aligned", l);
         }
     }
     a.eps = d->ln_eps;

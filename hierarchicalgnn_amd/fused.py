@@ -339,10 +339,12 @@ def _split3_weight(weight, kept_cols, panels: bool):
     return Wv
 
 
-def _split3_applies(net, segments) -> bool:
-    """the opt-in split-bf16 path is switched on for this network and hgnn_mlp_forward_f32_split3 has its shape"""
-    if not (_fp32_split3 or getattr(net, "_hgnn_split3", False)) or torch.is_grad_enabled() and any(
-            p.requires_grad for p in net.parameters()):
+def _split3_applies(net, segments, training: bool = False) -> bool:
+    """the opt-in split-bf16 path is switched on for this network and hgnn_mlp_forward_f32_split3 has its shape
+    (``training``: the call comes from the differentiable forward, which dumps the pre-LayerNorm rows)"""
+    if not (_fp32_split3 or getattr(net, "_hgnn_split3", False)):
+        return False
+    if not training and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
         return False
     layers = _parse(net)
     if layers is None or len(layers) not in (2, 3) or any(ln is None for _, ln, _ in layers):
@@ -354,9 +356,9 @@ def _split3_applies(net, segments) -> bool:
     return head_body or (o in (128, 256) and all(lin.out_features == 2 * o for lin, _, _ in layers[:-1]))
 
 
-def _try_split3(net, segments, d, keep):
+def _try_split3(net, segments, d, keep, training: bool = False):
     """re-point a ready fp32 descriptor at split-3 weight streams if the opt-in path supports its shape"""
-    if not _split3_applies(net, segments) or int(d.w0_cols) != 0 or int(d.w_last_rows) != 0:
+    if not _split3_applies(net, segments, training) or int(d.w0_cols) != 0 or int(d.w_last_rows) != 0:
         return False
     layers = _parse(net)
     kept = None
@@ -735,8 +737,15 @@ class _FusedMLPTrain(torch.autograd.Function):
         out = torch.empty((M, n_out), dtype=torch.float32, device=dev)
         if M:
             with torch.cuda.device(dev):
-                _lib.check(_lib.load().hgnn_mlp_forward_f32(ctypes.byref(d), _lib.ptr(out),
-                                                            _lib.current_stream(dev)), "hgnn_mlp_forward_f32")
+                if _try_split3(net, segments, d, keep, training=True):
+                    # opt-in: the forward (and its dumps) on the split-bf16 kernel; the backward below is unchanged
+                    _lib.check(_lib.load().hgnn_mlp_forward_f32_split3(ctypes.byref(d), _lib.ptr(out),
+                                                                       _lib.current_stream(dev)),
+                               "hgnn_mlp_forward_f32_split3")
+                    stats["split3_calls"] = stats.get("split3_calls", 0) + 1
+                else:
+                    _lib.check(_lib.load().hgnn_mlp_forward_f32(ctypes.byref(d), _lib.ptr(out),
+                                                                _lib.current_stream(dev)), "hgnn_mlp_forward_f32")
         del keep
         stats["fused_train_calls"] += 1
         ctx.indices, ctx.has_skip, ctx.n = indices, has_skip, n

@@ -344,7 +344,7 @@ int hgnn_mlp_rows128_enabled(void);
 
 /* fp32 rows, SPLIT-bf16 arithmetic (opt-in fast path of the fp32 MLPs at latent 128 / 256: K -> 2L (-> 2L) -> L, and
  * K -> H -> H with H in {256, 512} = the two hidden layers of a score head, whose plain last Linear the caller applies;
- * LayerNorm on every layer, every segment a multiple of 128 wide, n_pre allowed, no save_pre): every fp32 operand of
+ * LayerNorm on every layer, every segment a multiple of 128 wide, n_pre allowed, save_pre optional (fp32 dumps)): every fp32 operand of
  * the GEMMs is used as hi + mid with hi = bf16(x), mid = bf16(x - hi), and  x.w ~= hi.hi + mid.hi + hi.mid  runs as
  * three v_mfma_f32_16x16x32_bf16 (exact products, fp32 accumulation) instead of one fp32 MFMA at 1/16 of the rate.
  * Bias, LayerNorm, exact-erf GELU / tanh, skip and every row in HBM stay fp32.  Error at model level 2e-5 against the

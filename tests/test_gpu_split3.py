@@ -80,6 +80,24 @@ def test_split3_config2_ec_in_latent128_within_the_parity_bar(split3):
     assert_parity(scores, z["scores"], C.TOL, "scores")
 
 
+def test_split3_config2_training_step_gradients_within_the_bar(split3):
+    """training mode (the reference's reentrant checkpointing): forward passes and pre-LayerNorm dumps on the split-bf16
+    kernel, hand-written backward unchanged; input gradient and every weight-gradient sketch against the reference's"""
+    from hierarchicalgnn_amd.models import EC_InteractionGNN
+    z = load_golden("ec_in_L128.npz")
+    model = C._seeded(EC_InteractionGNN, C._cfg("EC-IN"), z)
+    x = torch.from_numpy(z["x"]).cuda().clone()
+    graph = torch.from_numpy(z["edge_index"]).cuda()
+    n0 = split3.stats.get("split3_calls", 0)
+    scores = model(x, graph)
+    assert x.requires_grad
+    (scores * torch.from_numpy(z["r_scores"]).cuda()).sum().backward()
+    assert split3.stats.get("split3_calls", 0) - n0 >= 2 * 2 * 14     # no-grad pass + recompute of every cell network
+    assert np.abs(scores.detach().cpu().numpy() - z["scores"]).max() <= C.TOL
+    assert_parity(x.grad, z["grad_x"], C.TOL, "d loss / d x")
+    C._sketch_close(model, z)
+
+
 def test_split3_by_hparams_only_marks_that_model():
     """hparams["fp32_gemm"] = "split_bf16" switches one model's networks; the process-wide default stays exact"""
     from hierarchicalgnn_amd import fused
