@@ -274,22 +274,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
     const int np = a.K1 / PK;
     const int p1 = a.seg_width[0] / PK;
     const int p2 = p1 + (a.n_seg > 1 ? a.seg_width[1] / PK : np);
-    constexpr int PPR = PHB / 16;
-    constexpr int NPI = 16 * PHB / 1024;
-    constexpr int IPW = NPI / NW;
-    static_assert(NPI % NW == 0, "P pass does not split over the waves");
+    // pre-projected gathered segments (fp32 rows) by LDS-DMA, WAVE-PRIVATE: a wave fetches only its own 64-feature slice
+    // (256 bytes) of the 16 rows of a pass into its own ring of four buffers, so the P phase needs no workgroup
+    // barrier at all (the first version moved whole rows and paid one barrier per pass: 8 per tile in a workgroup whose
+    // 8 waves are phase-locked anyway)
+    static_assert(NTH == 4, "a wave's slice of a projected row is 16 pieces of 16 bytes");
+    constexpr int FWB = NTH * 16 * 4;      // bytes of this wave's slice of a P row (256)
+    constexpr int RPI = 1024 / FWB;        // rows per DMA instruction (4)
+    constexpr int IPW = 16 / RPI;          // DMA instructions per wave and pass (4)
+    static_assert(NW * 4 * 16 * FWB <= REGION, "P ring does not fit");
     const int npass = a.n_pre * NJ;
-    // pre-projected gathered segments (fp32 rows): whole rows by LDS-DMA through a ring of four 16-row buffers
+    char* pring = smem + wave * (4 * 16 * FWB);
     auto pissue = [&](int p, const int32_t* ti) {
         const int sgm = p / NJ, j = p % NJ;
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
-            const int k = wave + i * NW;
-            const int gp = k * 64 + lane;
-            const int row = gp / PPR, pc = gp % PPR;
+            const int row = i * RPI + (lane >> 4), pc = lane & 15;
             const int r = ti[(3 + sgm) * TE + 16 * j + row];
-            const char* src = (const char*)(a.pre_table[sgm] + (size_t)r * H) + (((pc & ~15) | ((pc ^ row) & 15)) << 4);
-            dma_piece(src, lds_addr_of((float*)(smem + (p & 3) * 16 * PHB)) + (unsigned)k * 1024u);
+            const char* src = (const char*)(a.pre_table[sgm] + (size_t)r * H + wave * NTH * 16) + ((pc ^ row) << 4);
+            dma_piece(src, lds_addr_of((float*)(pring + (p & 3) * 16 * FWB)) + (unsigned)i * 1024u);
         }
     };
 
@@ -367,13 +370,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
                     if (p + 2 < npass) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
                     else if (p + 1 < npass) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    const char* buf = smem + (p & 3) * 16 * PHB + ei * PHB;
+                    const char* buf = pring + (p & 3) * 16 * FWB + ei * FWB;
 #pragma unroll
-                    for (int t = 0; t < NTH; ++t) {
-                        const int q = 4 * (wave * NTH + t) + g;
-                        acc1[t][p % NJ] += *(const f32x4*)(buf + (((q & ~15) | ((q ^ ei) & 15)) << 4));
-                    }
+                    for (int t = 0; t < NTH; ++t)
+                        acc1[t][p % NJ] += *(const f32x4*)(buf + (((4 * t + g) ^ ei) << 4));
                     if (p + 3 < npass) pissue(p + 3, ti);
                 }
             }
