@@ -1,5 +1,6 @@
 // fp32 fused  gather -> concat -> [Linear -> LayerNorm -> act] x {2,3} -> (+skip)  MLP whose GEMMs run on the bf16
-// matrix pipe as SPLIT-bf16 products (opt-in: hgnn_mlp_forward_f32_split3).
+// matrix pipe as SPLIT-bf16 products (hgnn_mlp_forward_f32_split3; the Python layer's default fp32 MLP path at latent
+// 128 / 256, fused.set_fp32_split3).
 //
 // Every fp32 operand is written as  x = hi + mid (+ lo),  hi = bf16(x), mid = bf16(x - hi): 8 + 8 significand bits.
 // Products of bf16 parts are exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates them in fp32, so

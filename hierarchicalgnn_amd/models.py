@@ -30,13 +30,14 @@ def _bf16_features(hparams) -> bool:
 
 
 def _mark_split3(module, hparams):
-    """hparams["fp32_gemm"] = "split_bf16" (an MI355X-side switch, absent = exact fp32 matrix arithmetic): inference
-    forwards of this module's fp32 MLPs whose shape the kernel supports (node / edge / supernode / superedge networks
-    at latent 128 / 256) evaluate their GEMMs as split-bf16 products (fused.set_fp32_split3 is the process-wide form)"""
-    if str(hparams.get("fp32_gemm", "")).lower() in ("split_bf16", "split3"):
+    """hparams["fp32_gemm"] (an MI355X-side key): "split_bf16" / "exact" pin this module's fp32 MLPs to the split-bf16
+    evaluation of their GEMMs (fused.set_fp32_split3) or to the exact fp32 matrix instruction, whatever the
+    process-wide default is; absent = the process-wide default (split-bf16, HGNN_FP32_SPLIT3=0 switches it off)"""
+    mode = str(hparams.get("fp32_gemm", "")).lower()
+    if mode in ("split_bf16", "split3", "exact", "fp32"):
         for m in module.modules():
             if isinstance(m, nn.Sequential):
-                m._hgnn_split3 = True
+                m._hgnn_split3 = mode in ("split_bf16", "split3")
 
 
 def _head_input(t, hparams):

@@ -342,7 +342,7 @@ int hgnn_mlp_supported_bf16_rows128(const hgnn_mlp_desc* d);
 int hgnn_mlp_forward_bf16_rows128(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
 int hgnn_mlp_rows128_enabled(void);
 
-/* fp32 rows, SPLIT-bf16 arithmetic (opt-in fast path of the fp32 MLPs at latent 128 / 256: K -> 2L (-> 2L) -> L, and
+/* fp32 rows, SPLIT-bf16 arithmetic (the Python layer's default path of the fp32 MLPs at latent 128 / 256: K -> 2L (-> 2L) -> L, and
  * K -> H -> H with H in {256, 512} = the two hidden layers of a score head, whose plain last Linear the caller applies;
  * LayerNorm on every layer, every segment a multiple of 128 wide, n_pre allowed, save_pre optional (fp32 dumps)): every fp32 operand of
  * the GEMMs is used as hi + mid with hi = bf16(x), mid = bf16(x - hi), and  x.w ~= hi.hi + mid.hi + hi.mid  runs as

@@ -24,6 +24,23 @@ def pytest_sessionstart(session):
         b.build(verbose=False)
 
 
+@pytest.fixture(autouse=True)
+def _exact_fp32_matrix_arithmetic(request):
+    """The process default evaluates the fp32 MLPs' GEMMs as split-bf16 products (fused.set_fp32_split3, <= 1.6e-5 vs
+    the reference); the GPU parity tests pin the EXACT fp32 kernels unless they are the split-bf16 tests themselves
+    (tests/test_gpu_split3.py), so that both kernels stay covered.  The whole suite also passes with the default left
+    on (HGNN_KEEP_DEFAULT_FP32_GEMM=1 python -m pytest -m gpu; profiles/r02_gpu_suite_split3_on.txt)."""
+    if "gpu" not in request.keywords or request.module.__name__ == "test_gpu_split3" \
+            or os.environ.get("HGNN_KEEP_DEFAULT_FP32_GEMM") == "1":
+        yield
+        return
+    from hierarchicalgnn_amd import fused
+    old = fused._fp32_split3
+    fused.set_fp32_split3(False)
+    yield
+    fused.set_fp32_split3(old)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def split3():
     from hierarchicalgnn_amd import fused
+    old = fused._fp32_split3
     fused.set_fp32_split3(True)
     yield fused
-    fused.set_fp32_split3(False)
+    fused.set_fp32_split3(old)
 
 
 @pytest.mark.parametrize("L,layers,nseg,M", [(256, 2, 3, 1), (256, 2, 3, 333), (128, 2, 3, 1000), (256, 3, 2, 200),
@@ -98,15 +99,18 @@ def test_split3_config2_training_step_gradients_within_the_bar(split3):
     C._sketch_close(model, z)
 
 
-def test_split3_by_hparams_only_marks_that_model():
-    """hparams["fp32_gemm"] = "split_bf16" switches one model's networks; the process-wide default stays exact"""
+def test_split3_is_the_process_default_and_hparams_pin_a_model():
+    """default on (HGNN_FP32_SPLIT3 unset); hparams["fp32_gemm"] = "exact" / "split_bf16" pin one model either way"""
+    import os
     from hierarchicalgnn_amd import fused
     from hierarchicalgnn_amd.models import EC_InteractionGNN
+    if os.environ.get("HGNN_FP32_SPLIT3") is None:
+        assert fused._fp32_split3 is True
     z = load_golden("ec_in_L128.npz")
     x = torch.from_numpy(z["x"]).cuda()
     graph = torch.from_numpy(z["edge_index"]).cuda()
     fast = C._seeded(EC_InteractionGNN, dict(C._cfg("EC-IN"), fp32_gemm="split_bf16"), z)
-    exact = C._seeded(EC_InteractionGNN, C._cfg("EC-IN"), z)
+    exact = C._seeded(EC_InteractionGNN, dict(C._cfg("EC-IN"), fp32_gemm="exact"), z)
     with torch.inference_mode():
         n0 = fused.stats.get("split3_calls", 0)
         s_exact = exact(x, graph)

@@ -10,6 +10,7 @@ import torch
 import hierarchicalgnn_amd as H
 from hierarchicalgnn_amd import fused, make_mlp, mlp
 
+fused.set_fp32_split3(False)   # the exact fp32 kernels are the default subject; the split-bf16 path has its own block
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 g = torch.Generator().manual_seed(seed)
