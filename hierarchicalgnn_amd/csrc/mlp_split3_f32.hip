@@ -464,6 +464,96 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
     }
 }
 
+// out[M, N] = x[M, K] . W^T (+ skip): ONE plain fp32 Linear without bias / LayerNorm on the same split-bf16 loop -- the
+// M-row data-gradient GEMMs of the fp32 training backward (dz . W of Modules/utils.py:169-196's Linear under autograd;
+// the library's fp32 GEMM runs them at ~130 TFLOP/s).  N = NT NW 16; K a multiple of 128; W as in the MLP kernel.
+template <int NW, int NT>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_linear_f32_split3(const float* __restrict__ x, int K,
+                                                                               const unsigned short* __restrict__ W,
+                                                                               const float* __restrict__ skip,
+                                                                               float* __restrict__ out, long long M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTHR = NW * 64;
+    constexpr int N = NT * NW * 16;
+    constexpr int LPR = PK * 4 / 16;
+    constexpr int RPP = NTHR / LPR;
+    constexpr int NP = TE / RPP;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ei = lane & 15, g = lane >> 4;
+    const int prow = tid / LPR, pcol = tid % LPR;
+    const long long e0 = (long long)blockIdx.x * TE;
+    const float* px[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        long long e = e0 + i * RPP + prow;
+        if (e >= M) e = M - 1;
+        px[i] = x + (size_t)e * (size_t)K + pcol * 4;
+    }
+    f32x4 st[NP];
+    auto load_panel = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            st[i] = *(const f32x4*)px[i];
+            px[i] += PK;
+        }
+    };
+    auto store_panel = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            u16x4 h, m;
+            split4(st[i], h, m);
+            char* dst = smem + (2 * buf) * PANEL + (i * RPP + prow) * PRS + pcol * 8;
+            *(u16x4*)dst = h;
+            *(u16x4*)(dst + PANEL) = m;
+        }
+    };
+    f32x4 acc[NT][NJ];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int np = K / PK;
+    const int vtotal = 2 * (K / 32);
+    const u16x8* wp = (const u16x8*)W + (size_t)(wave * NT) * 64 + lane;
+    load_panel();
+    store_panel(0);
+    __syncthreads();
+    const char* blane = smem + ei * PRS + (g << 4);
+    for (int p = 0; p < np; ++p) {
+        const bool more = p + 1 < np;
+        if (more) load_panel();
+        const char* bh = blane + (2 * (p & 1)) * PANEL;
+        gemm3s<NT, PRS, NW>(acc, wp, 2 * p * CPP, vtotal, bh, bh + PANEL, CPP);
+        if (more) store_panel((p + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long e = e0 + j * 16 + ei;
+        if (e >= M) continue;
+        const size_t off = (size_t)e * N + (size_t)(wave * NT * 16 + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 v = acc[t][j];
+            if (skip != nullptr) v += *(const f32x4*)(skip + off + t * 16);
+            *(f32x4*)(out + off + t * 16) = v;
+        }
+    }
+}
+
+template <int NW, int NT>
+static int launch_linear(const float* x, int K, const unsigned short* W, const float* skip, float* out, long long M,
+                         hipStream_t s) {
+    const size_t lds_bytes = (size_t)4 * PANEL;
+    auto kern = k_linear_f32_split3<NW, NT>;
+    HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    kern<<<(unsigned)ceil_div(M, TE), NW * 64, lds_bytes, s>>>(x, K, W, skip, out, M);
+    HGNN_CHECK_HIP(hipGetLastError());
+    return HGNN_OK;
+}
+
 static int g_cus = 0;
 
 template <int NW, int NTH, int NTO, int NL>
@@ -574,4 +664,18 @@ extern "C" int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, h
     // tile against the tile's fixed costs)
     if (d->n_layers == 2) return o == 256 ? f3::launch<8, 4, 2, 2>(a, stream) : f3::launch<4, 4, 2, 2>(a, stream);
     return o == 256 ? f3::launch<8, 4, 2, 3>(a, stream) : f3::launch<4, 4, 2, 3>(a, stream);
+}
+
+extern "C" int hgnn_linear_f32_split3(const float* x, int64_t M, int32_t K, const void* w_split, int32_t N,
+                                      const float* skip, float* out, hgnn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HGNN_REQUIRE(M >= 0 && M <= 0x7fffffffLL && K > 0 && K % 128 == 0 && (N == 256 || N == 512),
+                 "hgnn_linear_f32_split3: M = %lld, K = %d (multiple of 128), N = %d (256 or 512)", (long long)M, K, N);
+    if (M == 0) return HGNN_OK;
+    HGNN_REQUIRE(x != nullptr && w_split != nullptr && out != nullptr, "hgnn_linear_f32_split3: NULL argument");
+    HGNN_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w_split % 16 == 0 && (uintptr_t)out % 16 == 0 &&
+                     (uintptr_t)skip % 16 == 0,
+                 "hgnn_linear_f32_split3: pointers must be 16-byte aligned");
+    if (N == 512) return f3::launch_linear<8, 4>(x, K, (const unsigned short*)w_split, skip, out, M, stream);
+    return f3::launch_linear<4, 4>(x, K, (const unsigned short*)w_split, skip, out, M, stream);
 }

@@ -320,20 +320,22 @@ def _split3_on(net) -> bool:
     return _fp32_split3 if flag is None else bool(flag)
 
 
-def _split3_weight(weight, kept_cols, panels: bool):
+def _split3_weight(weight, kept_cols, panels: bool, transpose: bool = False):
     """bf16 split stream of an fp32 Linear weight (per 32-wide k-chunk of the kept columns: W_hi, then W_mid) in
     A-fragment order, cached per weight version"""
     try:
         ver = weight._version
     except RuntimeError:
         ver = -1
-    key = (weight.data_ptr(), tuple(weight.shape), "split3", kept_cols, panels)
+    key = (weight.data_ptr(), tuple(weight.shape), "split3", kept_cols, panels, transpose)
     hit = _wcache.get(key) if ver >= 0 else None
     if hit is not None and hit[0] is weight and hit[1] == ver:
         return hit[2]
     W = weight.detach().float()
     if kept_cols is not None:
         W = torch.cat([W[:, c0:c1] for c0, c1 in kept_cols], dim=1)
+    if transpose:
+        W = W.t().contiguous()
     hi = W.to(torch.bfloat16)
     mid = (W - hi.float()).to(torch.bfloat16)
     F, K = W.shape
@@ -345,6 +347,27 @@ def _split3_weight(weight, kept_cols, panels: bool):
             _wcache.clear()
         _wcache[key] = (weight, ver, Wv)
     return Wv
+
+
+def _split3_linear(x: torch.Tensor, weight, cols, net) -> Optional[torch.Tensor]:
+    """x [M, K] . W[:, cols]  for a Linear weight W [K, in] (``cols`` = (c0, c1) or None): the data gradient dz . W of
+    the fp32 training backward as ONE split-bf16 GEMM (hgnn_linear_f32_split3), or None when the split-bf16 mode is
+    off / the shape has no instantiation (the caller then uses the library's fp32 GEMM)"""
+    K = int(x.shape[1])
+    N = int(weight.shape[1]) if cols is None else cols[1] - cols[0]
+    if not _split3_on(net) or x.dtype != torch.float32 or not x.is_cuda or K % 128 or N not in (256, 512) \
+            or int(x.shape[0]) == 0:
+        return None
+    # the kernel wants the weight of the Linear that maps K -> N, i.e. W[:, cols]^T  [N, K]
+    Wv = _split3_weight(weight, None if cols is None else (tuple(cols),), False, transpose=True)
+    xc = x if x.is_contiguous() else x.contiguous()
+    out = torch.empty((int(x.shape[0]), N), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().hgnn_linear_f32_split3(_lib.ptr(xc), int(x.shape[0]), K, _lib.ptr(Wv), N, None,
+                                                      _lib.ptr(out), _lib.current_stream(x.device)),
+                   "hgnn_linear_f32_split3")
+    stats["split3_linear_calls"] = stats.get("split3_linear_calls", 0) + 1
+    return out
 
 
 def _split3_applies(net, segments, training: bool = False) -> bool:
@@ -757,6 +780,7 @@ class _FusedMLPTrain(torch.autograd.Function):
         del keep
         stats["fused_train_calls"] += 1
         ctx.indices, ctx.has_skip, ctx.n = indices, has_skip, n
+        ctx.net = net
         ctx.acts = [int(d.act[l]) for l in range(n)]
         ctx.eps = float(d.ln_eps)
         ctx.save_for_backward(*tables, *params, *zs)
@@ -778,6 +802,7 @@ class _FusedMLPTrain(torch.autograd.Function):
         params = saved[n_seg:n_seg + 4 * n]
         zs = saved[n_seg + 4 * n:]
         W = [params[4 * l] for l in range(n)]
+        lw = [lin.weight for lin, _, _ in _parse(ctx.net)]   # the Parameter objects themselves (weight-prep cache keys)
         lnw = [params[4 * l + 2] for l in range(n)]
         lnb = [params[4 * l + 3] for l in range(n)]
         aten = torch.ops.aten
@@ -827,7 +852,9 @@ class _FusedMLPTrain(torch.autograd.Function):
             grads_params[4 * l + 3] = dlb
             if l > 0:
                 grads_params[4 * l] = _atb(dz, outs[l - 1])
-                da = dz @ W[l]
+                da = _split3_linear(dz, lw[l], None, ctx.net)
+                if da is None:
+                    da = dz @ W[l]
                 outs[l - 1] = None
             else:
                 # First layer.  A gathered segment x_s = table[idx] enters linearly, so both of its
@@ -853,7 +880,8 @@ class _FusedMLPTrain(torch.autograd.Function):
                     else:
                         dW_cols.append(_atb(dz, tab))
                         if ctx.needs_input_grad[3 + s_i]:
-                            grads_tables[s_i] = dz @ W_s
+                            gt = _split3_linear(dz, lw[0], (col, col + w_s), ctx.net)
+                            grads_tables[s_i] = gt if gt is not None else dz @ W_s
                     col += w_s
                 grads_params[0] = dW_cols[0] if n_seg == 1 else torch.cat(dW_cols, dim=1)
         grad_skip = [g] if ctx.has_skip else []

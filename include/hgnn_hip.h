@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 19
+#define HGNN_ABI_VERSION 20
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -355,6 +355,12 @@ int hgnn_mlp_rows128_enabled(void);
  * hgnn_mlp_forward_bf16_split. */
 int hgnn_mlp_supported_f32_split3(const hgnn_mlp_desc* d);
 int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, hgnn_stream_t stream);
+
+/* out[M, N] = x[M, K] . W^T (+ skip), all fp32 in HBM, the product as split-bf16 (same arithmetic and the same
+ * weight stream layout as hgnn_mlp_forward_f32_split3: w_split = the split stream of W [N, K]): the M-row data-gradient
+ * GEMMs of the fp32 training backward.  K a multiple of 128, N in {256, 512}; skip [M, N] or NULL. */
+int hgnn_linear_f32_split3(const float* x, int64_t M, int32_t K, const void* w_split, int32_t N,
+                           const float* skip, float* out, hgnn_stream_t stream);
 
 /* LayerNorm + activation of one make_mlp layer (Modules/utils.py:169-196: Linear -> LayerNorm ->
  * act) over rows z[M, W] (the Linear's output, as dumped by hgnn_mlp_forward_f32's save_pre), one

@@ -81,6 +81,23 @@ def test_split3_config2_ec_in_latent128_within_the_parity_bar(split3):
     assert_parity(scores, z["scores"], C.TOL, "scores")
 
 
+@pytest.mark.parametrize("M,K,N,cols", [(1, 256, 512, None), (333, 256, 512, None), (5000, 512, 256, (256, 512)),
+                                        (70001, 512, 256, (0, 256)), (64, 128, 256, None)])
+def test_split3_linear_data_gradient_vs_fp64(split3, M, K, N, cols):
+    """dz . W[:, cols] (hgnn_linear_f32_split3): the M-row data-gradient GEMMs of the fp32 training backward"""
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    n_in = N if cols is None else 3 * N
+    lin = torch.nn.Linear(n_in, K).cuda()                       # weight [K, n_in]
+    dz = torch.randn(M, K, device="cuda", generator=g)
+    n0 = split3.stats.get("split3_linear_calls", 0)
+    out = split3._split3_linear(dz, lin.weight, cols, torch.nn.Sequential())
+    assert out is not None and split3.stats.get("split3_linear_calls", 0) == n0 + 1
+    W = lin.weight.detach().double()
+    ref = dz.double() @ (W if cols is None else W[:, cols[0]:cols[1]])
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+
+
 def test_split3_config2_training_step_gradients_within_the_bar(split3):
     """training mode (the reference's reentrant checkpointing): forward passes and pre-LayerNorm dumps on the split-bf16
     kernel, hand-written backward unchanged; input gradient and every weight-gradient sketch against the reference's"""
