@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("HGNN_LIB") or os.path.join(_HERE, "csrc", "libhgnn_hi
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 20
+ABI_VERSION = 21
 MLP_BWD_BLOCKS = 512   # HGNN_MLP_BWD_BLOCKS
 GMM_STATE, GMM_BLOCKS = 16, 1024   # HGNN_GMM_STATE, HGNN_GMM_BLOCKS
 LN_ACT_BLOCKS = 1024   # HGNN_LN_ACT_BLOCKS
@@ -92,6 +92,8 @@ _SIGNATURES = {
                                           c_float, c_void_p, c_void_p, c_void_p]),
     "hgnn_wgrad_workspace_bytes": (c_int, [c_int64, c_int32, c_int32, POINTER(c_size_t)]),
     "hgnn_wgrad_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_int64,
+                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hgnn_wgrad_f32_split3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_int64,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
     "hgnn_mlp_backward_layer_supported_bf16": (c_int, [c_int32, c_int32]),
     "hgnn_mlp_backward_layer_bf16": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -40,8 +40,22 @@ __device__ __forceinline__ bf16x8 tr_operand(const char* tile, int stride, int c
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// TO x TI output tile per workgroup, WO x WI waves, each wave (TO/WO) x (TI/WI)
-template <int TO, int TI, int WO, int WI>
+// (hi, mid) bf16 parts of 8 fp32 values: x ~= hi + mid to 16 significand bits (split-bf16 products, mlp_split3_f32.hip)
+__device__ __forceinline__ void split8(const f32x4 lo4, const f32x4 hi4, u16x8& h, u16x8& m) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float x = c < 4 ? lo4[c] : hi4[c - 4];
+        const __bf16 hb = (__bf16)x;
+        h[c] = __builtin_bit_cast(unsigned short, hb);
+        m[c] = __builtin_bit_cast(unsigned short, (__bf16)(x - (float)hb));
+    }
+}
+
+// TO x TI output tile per workgroup, WO x WI waves, each wave (TO/WO) x (TI/WI).
+// S3: the operands are FP32 rows (A, B point at floats, lda / ldb count floats); every tile is split into a hi and a
+// mid bf16 plane while it is written to LDS and  dz^T a ~= mid.hi + hi.mid + hi.hi  runs as three MFMAs -- the weight
+// gradient of the fp32 training backward at 3/16 of the fp32 matrix instruction's time (hgnn_wgrad_f32_split3).
+template <int TO, int TI, int WO, int WI, bool S3 = false>
 __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned short* __restrict__ A, long long lda,
                                                              const unsigned short* __restrict__ B, long long ldb,
                                                              long long M, int Ho, int Hi, float* __restrict__ partial,
@@ -55,6 +69,7 @@ __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned shor
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
     char* Bs = smem + 2 * KT * SA;
+    constexpr int MID = 2 * KT * (SA + SB);   // S3: the mid planes follow the hi planes
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,7 +83,33 @@ __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned shor
     const int steps = m_end > m_begin ? (int)((m_end - m_begin + KT - 1) / KT) : 0;
 
     u16x8 ra[NPA], rb[NPB];
+    f32x4 fa[S3 ? NPA : 1][2], fb[S3 ? NPB : 1][2];
     auto load = [&](int s) {
+        if constexpr (S3) {
+            const long long m0 = m_begin + (long long)s * KT;
+            const float* Af = (const float*)A;
+            const float* Bf = (const float*)B;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) {
+                const int idx = tid + i * NTHR;
+                const int row = idx / PA, col = ho0 + (idx % PA) * 8;
+                const bool ok = m0 + row < m_end && col < Ho;
+                const float* p = Af + (size_t)(m0 + row) * (size_t)lda + col;
+                fa[i][0] = ok ? *(const f32x4*)p : z4;
+                fa[i][1] = ok ? *(const f32x4*)(p + 4) : z4;
+            }
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) {
+                const int idx = tid + i * NTHR;
+                const int row = idx / PB, col = hi0 + (idx % PB) * 8;
+                const bool ok = m0 + row < m_end && col < Hi;
+                const float* p = Bf + (size_t)(m0 + row) * (size_t)ldb + col;
+                fb[i][0] = ok ? *(const f32x4*)p : z4;
+                fb[i][1] = ok ? *(const f32x4*)(p + 4) : z4;
+            }
+            return;
+        }
         const long long m0 = m_begin + (long long)s * KT;
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
@@ -86,6 +127,27 @@ __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned shor
         }
     };
     auto store = [&](int buf) {
+        if constexpr (S3) {
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) {
+                const int idx = tid + i * NTHR;
+                u16x8 h, m;
+                split8(fa[i][0], fa[i][1], h, m);
+                char* d = As + buf * KT * SA + (idx / PA) * SA + (idx % PA) * 16;
+                *(u16x8*)d = h;
+                *(u16x8*)(d + MID) = m;
+            }
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) {
+                const int idx = tid + i * NTHR;
+                u16x8 h, m;
+                split8(fb[i][0], fb[i][1], h, m);
+                char* d = Bs + buf * KT * SB + (idx / PB) * SB + (idx % PB) * 16;
+                *(u16x8*)d = h;
+                *(u16x8*)(d + MID) = m;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
             const int idx = tid + i * NTHR;
@@ -125,13 +187,34 @@ __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned shor
         bf16x8 b[FI];
 #pragma unroll
         for (int fi = 0; fi < FI; ++fi) b[fi] = tr_operand(bt, SB, wi * (TI / WI) + fi * 16, lane);
+        if constexpr (S3) {
+            bf16x8 bm[FI];
 #pragma unroll
-        for (int fo = 0; fo < FO; ++fo) {
-            const bf16x8 a = tr_operand(at, SA, wo * (TO / WO) + fo * 16, lane);
+            for (int fi = 0; fi < FI; ++fi) bm[fi] = tr_operand(bt + MID, SB, wi * (TI / WI) + fi * 16, lane);
 #pragma unroll
-            for (int fi = 0; fi < FI; ++fi)
-                acc[fo][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[fi], acc[fo][fi], 0, 0, 0);
-            if (do_cs) acs[fo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, acs[fo], 0, 0, 0);
+            for (int fo = 0; fo < FO; ++fo) {
+                const bf16x8 a = tr_operand(at, SA, wo * (TO / WO) + fo * 16, lane);
+                const bf16x8 am = tr_operand(at + MID, SA, wo * (TO / WO) + fo * 16, lane);
+#pragma unroll
+                for (int fi = 0; fi < FI; ++fi) {
+                    acc[fo][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b[fi], acc[fo][fi], 0, 0, 0);
+                    acc[fo][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bm[fi], acc[fo][fi], 0, 0, 0);
+                    acc[fo][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[fi], acc[fo][fi], 0, 0, 0);
+                }
+                if (do_cs) {
+                    acs[fo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, ones, acs[fo], 0, 0, 0);
+                    acs[fo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, acs[fo], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int fo = 0; fo < FO; ++fo) {
+                const bf16x8 a = tr_operand(at, SA, wo * (TO / WO) + fo * 16, lane);
+#pragma unroll
+                for (int fi = 0; fi < FI; ++fi)
+                    acc[fo][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[fi], acc[fo][fi], 0, 0, 0);
+                if (do_cs) acs[fo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, acs[fo], 0, 0, 0);
+            }
         }
         if (more) store((s + 1) & 1);
         __syncthreads();
@@ -257,6 +340,44 @@ extern "C" int hgnn_wgrad_bf16(const void* A, int64_t lda, const void* B, int64_
         wg::k_wgrad_bf16<TO, TI, 2, 2><<<grid, 256, lds, stream>>>((const unsigned short*)A, lda, (const unsigned short*)B,
                                                                    ldb, M, Ho, Hi, partial, s.rows_per_slice, partial_cs);
     }
+    wg::k_wgrad_reduce<<<(unsigned)ceil_div((int64_t)Ho * Hi, 256), 256, 0, stream>>>(partial, s.slices, Ho, Hi, out, ldo,
+                                                                                      partial_cs, colsum);
+    HGNN_CHECK_HIP(hipGetLastError());
+    return HGNN_OK;
+}
+
+/* the same weight gradient for FP32 rows, products as split-bf16 (hi.hi + mid.hi + hi.mid): see k_wgrad_bf16<.., S3> */
+extern "C" int hgnn_wgrad_f32_split3(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int32_t Ho,
+                                     int32_t Hi, float* out, int64_t ldo, float* colsum, void* workspace,
+                                     size_t workspace_bytes, hgnn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HGNN_REQUIRE(M >= 0 && Ho > 0 && Hi > 0 && Ho % 8 == 0 && Hi % 8 == 0,
+                 "hgnn_wgrad_f32_split3: Ho and Hi must be positive multiples of 8 (got %d, %d)", Ho, Hi);
+    HGNN_REQUIRE(out != nullptr && ldo >= Hi, "hgnn_wgrad_f32_split3: out is NULL or ldo < Hi");
+    HGNN_REQUIRE(lda >= Ho && ldb >= Hi && lda % 4 == 0 && ldb % 4 == 0,
+                 "hgnn_wgrad_f32_split3: row strides must be multiples of 4 floats and cover the columns");
+    HGNN_REQUIRE(M == 0 || (A != nullptr && B != nullptr && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0),
+                 "hgnn_wgrad_f32_split3: operands are NULL or not 16-byte aligned");
+    const wg::Shape s = wg::shape_for(M, Ho, Hi);
+    const size_t need = (size_t)s.slices * ((size_t)Ho * (size_t)Hi + (size_t)Ho) * sizeof(float);
+    HGNN_REQUIRE(workspace != nullptr && workspace_bytes >= need && (uintptr_t)workspace % 16 == 0,
+                 "hgnn_wgrad_f32_split3: workspace too small (%zu < %zu) or unaligned", workspace_bytes, need);
+    float* partial = (float*)workspace;
+    float* partial_cs = colsum != nullptr ? partial + (size_t)s.slices * (size_t)Ho * (size_t)Hi : nullptr;
+    const dim3 grid((unsigned)s.tiles, (unsigned)s.slices);
+    const unsigned short* Au = (const unsigned short*)A;
+    const unsigned short* Bu = (const unsigned short*)B;
+#define HGNN_WG3(TO_, TI_, WO_, WI_)                                                                              \
+    do {                                                                                                          \
+        const size_t lds = 2 * 2 * wg::KT * (size_t)((TO_ * 2 + 32) + (TI_ * 2 + 32));                            \
+        auto kern = wg::k_wgrad_bf16<TO_, TI_, WO_, WI_, true>;                                                   \
+        HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<grid, WO_ * WI_ * 64, lds, stream>>>(Au, lda, Bu, ldb, M, Ho, Hi, partial, s.rows_per_slice, partial_cs); \
+    } while (0)
+    if (s.to == 256 && s.ti == 256) HGNN_WG3(256, 256, 2, 4);
+    else if (s.to == 256) HGNN_WG3(256, 128, 4, 2);
+    else HGNN_WG3(128, 128, 2, 2);
+#undef HGNN_WG3
     wg::k_wgrad_reduce<<<(unsigned)ceil_div((int64_t)Ho * Hi, 256), 256, 0, stream>>>(partial, s.slices, Ho, Hi, out, ldo,
                                                                                       partial_cs, colsum);
     HGNN_CHECK_HIP(hipGetLastError());

@@ -722,12 +722,19 @@ def _ln_act_backward(z, grad_out, gamma, beta, act, eps):
     return dz, sums[0], sums[1], sums[2]
 
 
-def _atb(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
-    """A^T B for tall A [n, p], B [n, q] with a small [p, q] result: a weight gradient.  The library picks
+def _atb(A: torch.Tensor, B: torch.Tensor, net=None) -> torch.Tensor:
+    """A^T B for tall A [n, p], B [n, q] with a small [p, q] result: a weight gradient.  With the split-bf16 mode on
+    (``net`` given) and fp32 operands of at least 4096 rows: the hand-written split-K kernel on the bf16 matrix pipe
+    (ops.wgrad_f32_split3: ~1.7 ms where the library paths below need 3.6-4 ms at n = 2M).  Otherwise: the library picks
     a small output tile without split-K for these (p*q/1024 workgroups walking all n rows: 1.2 ms for the
     8 GFLOP of n = 120k, ~110 TFLOP/s at n = 2M); a batched product over row blocks plus one sum fills the
     chip (fixed summation order: deterministic).  EC-IN training step 368 -> 306 ms."""
     n = int(A.shape[0])
+    if net is not None and _split3_on(net) and n >= 4096 and A.dtype == torch.float32 and B.dtype == torch.float32 \
+            and A.is_cuda and int(A.shape[1]) % 8 == 0 and int(B.shape[1]) % 8 == 0:
+        from .ops import wgrad_f32_split3
+        stats["split3_wgrad_calls"] = stats.get("split3_wgrad_calls", 0) + 1
+        return wgrad_f32_split3(A, B)
     chunks = max(16, min(256, n // 8192))   # 4096 / 8192 rows per block measured equal, 32768 6 % slower
     c = n // chunks
     if c < 256:
@@ -851,7 +858,7 @@ class _FusedMLPTrain(torch.autograd.Function):
             grads_params[4 * l + 2] = dlw
             grads_params[4 * l + 3] = dlb
             if l > 0:
-                grads_params[4 * l] = _atb(dz, outs[l - 1])
+                grads_params[4 * l] = _atb(dz, outs[l - 1], ctx.net)
                 da = _split3_linear(dz, lw[l], None, ctx.net)
                 if da is None:
                     da = dz @ W[l]
@@ -873,12 +880,12 @@ class _FusedMLPTrain(torch.autograd.Function):
                     W_s = W[0][:, col:col + w_s]
                     if idx is not None:
                         S = _seg_reduce(get_plan(idx, int(tab.shape[0])), dz, None, None)
-                        dW_cols.append(_atb(S, tab))
+                        dW_cols.append(_atb(S, tab, ctx.net))
                         if ctx.needs_input_grad[3 + s_i]:
                             grads_tables[s_i] = S @ W_s
                         del S
                     else:
-                        dW_cols.append(_atb(dz, tab))
+                        dW_cols.append(_atb(dz, tab, ctx.net))
                         if ctx.needs_input_grad[3 + s_i]:
                             gt = _split3_linear(dz, lw[0], (col, col + w_s), ctx.net)
                             grads_tables[s_i] = gt if gt is not None else dz @ W_s

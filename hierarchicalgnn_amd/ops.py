@@ -380,3 +380,39 @@ def wgrad_bf16(dz: torch.Tensor, rows: torch.Tensor, out: Optional[torch.Tensor]
                                        ctypes.c_void_p(colsum.data_ptr()) if colsum is not None else None,
                                        _lib.ptr(ws), ws.numel(), _lib.current_stream(dz.device)), "hgnn_wgrad_bf16")
     return out
+
+
+def wgrad_f32_split3(dz: torch.Tensor, rows: torch.Tensor, out: Optional[torch.Tensor] = None,
+                     colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``dz^T @ rows`` for FP32 ``dz[M, Ho]`` and ``rows[M, Hi]`` with the products evaluated as split-bf16
+    (``hgnn_wgrad_f32_split3``: hi.hi + mid.hi + hi.mid on the bf16 matrix pipe, fp32 accumulation, deterministic):
+    the M-row weight gradients of the fp32 training backward.  Same conventions as :func:`wgrad_bf16`."""
+    _require_hip(dz, "dz")
+    _require_hip(rows, "rows")
+    if dz.dtype != torch.float32 or rows.dtype != torch.float32 or dz.dim() != 2 or rows.dim() != 2 \
+            or dz.shape[0] != rows.shape[0]:
+        raise RuntimeError("wgrad_f32_split3: fp32 dz[M, Ho] and rows[M, Hi] expected")
+    if dz.stride(1) != 1 or (dz.shape[0] > 1 and dz.stride(0) % 4) or dz.data_ptr() % 16:
+        dz = dz.contiguous()
+    if rows.stride(1) != 1 or (rows.shape[0] > 1 and rows.stride(0) % 4) or rows.data_ptr() % 16:
+        rows = rows.contiguous()
+    M, Ho, Hi = int(dz.shape[0]), int(dz.shape[1]), int(rows.shape[1])
+    if out is None:
+        out = torch.empty((Ho, Hi), dtype=torch.float32, device=dz.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (Ho, Hi) or out.stride(1) != 1:
+        raise RuntimeError("wgrad_f32_split3: out must be fp32 [Ho, Hi] with unit column stride")
+    lib = _lib.load()
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.hgnn_wgrad_workspace_bytes(M, Ho, Hi, ctypes.byref(nbytes)), "hgnn_wgrad_workspace_bytes")
+    ws = torch.empty(max(nbytes.value, 16), dtype=torch.uint8, device=dz.device)
+    lda = int(dz.stride(0)) if M > 1 else Ho
+    ldb = int(rows.stride(0)) if M > 1 else Hi
+    with torch.cuda.device(dz.device):
+        if colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != Ho or not colsum.is_contiguous()):
+            raise RuntimeError("wgrad_f32_split3: colsum must be a contiguous fp32 [Ho] tensor")
+        _lib.check(lib.hgnn_wgrad_f32_split3(_lib.ptr(dz), lda, _lib.ptr(rows), ldb, M, Ho, Hi,
+                                             ctypes.c_void_p(out.data_ptr()), int(out.stride(0)),
+                                             ctypes.c_void_p(colsum.data_ptr()) if colsum is not None else None,
+                                             _lib.ptr(ws), ws.numel(), _lib.current_stream(dz.device)),
+                   "hgnn_wgrad_f32_split3")
+    return out

@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 20
+#define HGNN_ABI_VERSION 21
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -400,6 +400,14 @@ int hgnn_wgrad_workspace_bytes(int64_t M, int32_t Ho, int32_t Hi, size_t* bytes)
 int hgnn_wgrad_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int32_t Ho, int32_t Hi,
                     float* out, int64_t ldo, float* colsum /* [Ho] = sum_m A[m, ho] (the bias gradient), or NULL */,
                     void* workspace, size_t workspace_bytes, hgnn_stream_t stream);
+
+/* the same weight gradient for FP32 rows dz [M, Ho] / a [M, Hi] (lda / ldb in floats, multiples of 4, 16-byte aligned
+ * rows), the products as split-bf16 (hi.hi + mid.hi + hi.mid, exact products, fp32 accumulation; see
+ * hgnn_mlp_forward_f32_split3): the M-row weight-gradient GEMMs of the fp32 training backward.  Workspace as
+ * hgnn_wgrad_workspace_bytes. */
+int hgnn_wgrad_f32_split3(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int32_t Ho, int32_t Hi,
+                          float* out, int64_t ldo, float* colsum, void* workspace, size_t workspace_bytes,
+                          hgnn_stream_t stream);
 
 /* hgnn_mlp_backward_layer_bf16: the hand-written DATA gradient of one Linear of the bf16 training path, fused with
  * what follows it in the backward:

@@ -98,6 +98,25 @@ def test_split3_linear_data_gradient_vs_fp64(split3, M, K, N, cols):
     assert float((out.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize("M,Ho,Hi", [(1000, 64, 64), (4097, 512, 256), (33, 256, 512), (70000, 256, 128), (7, 8, 24), (0, 64, 64)])
+def test_split3_weight_gradient_vs_fp64(M, Ho, Hi):
+    """dz^T rows for fp32 operands (hgnn_wgrad_f32_split3): the M-row weight gradients of the fp32 training backward"""
+    from hierarchicalgnn_amd.ops import wgrad_f32_split3
+    g = torch.Generator(device="cuda").manual_seed(M + Ho)
+    dz = torch.randn(M, Ho, device="cuda", generator=g)
+    rows = torch.randn(M, Hi, device="cuda", generator=g)
+    cs = torch.empty(Ho, device="cuda")
+    out = wgrad_f32_split3(dz, rows, colsum=cs)
+    ref = dz.double().t() @ rows.double()
+    assert out.shape == (Ho, Hi) and out.dtype == torch.float32
+    if M:
+        assert float((out.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+        assert float((cs.double() - dz.double().sum(0)).abs().max() / dz.double().sum(0).abs().max()) <= 2e-5
+    else:
+        assert float(out.abs().max()) == 0.0
+    assert torch.equal(out, wgrad_f32_split3(dz, rows))                # deterministic
+
+
 def test_split3_config2_training_step_gradients_within_the_bar(split3):
     """training mode (the reference's reentrant checkpointing): forward passes and pre-LayerNorm dumps on the split-bf16
     kernel, hand-written backward unchanged; input gradient and every weight-gradient sketch against the reference's"""
