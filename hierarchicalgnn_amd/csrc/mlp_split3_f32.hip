@@ -171,7 +171,9 @@ __device__ __forceinline__ void write_hidden2(const f32x4 (&acc)[NT][NJ], char* 
 // fragment is fetched ONCE and feeds both operand planes (the first version streamed [W_hi | W_hi | W_mid] through
 // three passes of the bf16 kernel's loop: 1.5 MiB of L2 reads per 64-row tile, L2-bound at 8.0 ms; now 1.0 MiB).
 // Everything is double-buffered one chunk ahead: a chunk is 3 NT NJ MFMAs (768 cycles at NT = 4).
-template <int NT, int RS, int NW>
+// FOUR: also the mid.mid product (2^-16 of a term: halves the truncation error; the data-gradient GEMMs of the
+// training backward use it, gradients pass through a dozen of these before they reach the first cell)
+template <int NT, int RS, int NW, bool FOUR = false>
 __device__ __forceinline__ void gemm3s(f32x4 (&acc)[NT][NJ], const u16x8* __restrict__ wp, int gv0, int vtotal,
                                        const char* b_hi, const char* b_mid, int n) {
     constexpr int VS = NW * NT * 64;   // u16x8 units per virtual chunk
@@ -208,12 +210,14 @@ __device__ __forceinline__ void gemm3s(f32x4 (&acc)[NT][NJ], const u16x8* __rest
             for (int t = 0; t < NT; ++t) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
+                    if constexpr (FOUR)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(wm[u][t]), as_bf16(bm[u][j]), acc[t][j], 0, 0, 0);
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(wm[u][t]), as_bf16(bh[u][j]), acc[t][j], 0, 0, 0);
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(wh[u][t]), as_bf16(bm[u][j]), acc[t][j], 0, 0, 0);
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(wh[u][t]), as_bf16(bh[u][j]), acc[t][j], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT * NJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, (FOUR ? 4 : 3) * NT * NJ, 0);
         }
     }
 }
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_linear_f32_split3(
         const bool more = p + 1 < np;
         if (more) load_panel();
         const char* bh = blane + (2 * (p & 1)) * PANEL;
-        gemm3s<NT, PRS, NW>(acc, wp, 2 * p * CPP, vtotal, bh, bh + PANEL, CPP);
+        gemm3s<NT, PRS, NW, true>(acc, wp, 2 * p * CPP, vtotal, bh, bh + PANEL, CPP);
         if (more) store_panel((p + 1) & 1);
         __syncthreads();
     }

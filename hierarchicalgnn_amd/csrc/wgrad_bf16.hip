@@ -53,7 +53,7 @@ __device__ __forceinline__ void split8(const f32x4 lo4, const f32x4 hi4, u16x8& 
 
 // TO x TI output tile per workgroup, WO x WI waves, each wave (TO/WO) x (TI/WI).
 // S3: the operands are FP32 rows (A, B point at floats, lda / ldb count floats); every tile is split into a hi and a
-// mid bf16 plane while it is written to LDS and  dz^T a ~= mid.hi + hi.mid + hi.hi  runs as three MFMAs -- the weight
+// mid bf16 plane while it is written to LDS and  dz^T a ~= mid.mid + mid.hi + hi.mid + hi.hi  runs as four MFMAs -- the weight
 // gradient of the fp32 training backward at 3/16 of the fp32 matrix instruction's time (hgnn_wgrad_f32_split3).
 template <int TO, int TI, int WO, int WI, bool S3 = false>
 __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned short* __restrict__ A, long long lda,
@@ -197,6 +197,9 @@ __global__ __launch_bounds__(WO * WI * 64) void k_wgrad_bf16(const unsigned shor
                 const bf16x8 am = tr_operand(at + MID, SA, wo * (TO / WO) + fo * 16, lane);
 #pragma unroll
                 for (int fi = 0; fi < FI; ++fi) {
+                    // four products: the kernel is an HBM stream, the mid.mid term (2^-16 of a product) is free here
+                    // and halves the truncation error of a reduction over millions of rows
+                    acc[fo][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[fi], acc[fo][fi], 0, 0, 0);
                     acc[fo][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, b[fi], acc[fo][fi], 0, 0, 0);
                     acc[fo][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bm[fi], acc[fo][fi], 0, 0, 0);
                     acc[fo][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[fi], acc[fo][fi], 0, 0, 0);

@@ -303,13 +303,29 @@ def _split_forward(d, out, dev):
 _fp32_split3 = os.environ.get("HGNN_FP32_SPLIT3", "1") != "0"
 
 
+_fp32_split3_train = os.environ.get("HGNN_FP32_SPLIT3_TRAIN", "0") == "1"
+
+
+def set_fp32_split3_training(flag: bool) -> None:
+    """OPT-IN (HGNN_FP32_SPLIT3_TRAIN=1): the split-bf16 arithmetic also under autograd -- the differentiable forward
+    with its pre-LayerNorm dumps (hgnn_mlp_forward_f32_split3), the M-row data gradients dz.W (hgnn_linear_f32_split3,
+    four products) and weight gradients dz^T a (hgnn_wgrad_f32_split3) of the backward.  EC-IN fp32 training step at
+    latent 256: 883 -> 568 ms, latent 128 285 -> 235 ms, config 3 744 -> 486 ms.  Every gradient bar of the GPU suite
+    holds with it on (269 passed), normwise with >= 6x margin, but the ELEMENT-WISE 1e-4 bar only by 3-7 % on two
+    fixtures (9.3e-5 on one weight gradient of the latent-256 HGNN cell, 7.8e-5 on config 2's input gradient): by
+    default gradients are therefore computed on the exact fp32 path and only no-grad forwards (inference, and the
+    no-grad pass of a reentrant checkpoint) use split-bf16."""
+    global _fp32_split3_train
+    _fp32_split3_train = bool(flag)
+
+
 def set_fp32_split3(flag: bool) -> None:
     """The forwards of the fp32 MLPs at latent 128 / 256 (node / edge / supernode / superedge networks, the hidden layers
     of the score heads; inference and the forward passes of a training step) evaluate their GEMMs as split-bf16
     products on the bf16 matrix pipe (hgnn_mlp_forward_f32_split3: hi.hi + mid.hi + hi.mid, exact products, fp32
     accumulation; rows, LayerNorm, activations, skip in fp32): <= 1.6e-5 against the reference at every checked stage
     of BASELINE configs 2 and 3, inside north_star's 1e-4, and the whole GPU parity suite holds with it on.
-    DEFAULT ON; ``set_fp32_split3(False)``, ``HGNN_FP32_SPLIT3=0`` or ``hparams["fp32_gemm"] = "exact"`` select the
+    DEFAULT ON for no-grad forwards (set_fp32_split3_training switches it on under autograd too); ``set_fp32_split3(False)``, ``HGNN_FP32_SPLIT3=0`` or ``hparams["fp32_gemm"] = "exact"`` select the
     exact fp32 matrix instruction (fmaf-chain arithmetic) instead."""
     global _fp32_split3
     _fp32_split3 = bool(flag)
@@ -355,7 +371,8 @@ def _split3_linear(x: torch.Tensor, weight, cols, net) -> Optional[torch.Tensor]
     off / the shape has no instantiation (the caller then uses the library's fp32 GEMM)"""
     K = int(x.shape[1])
     N = int(weight.shape[1]) if cols is None else cols[1] - cols[0]
-    if not _split3_on(net) or x.dtype != torch.float32 or not x.is_cuda or K % 128 or N not in (256, 512) \
+    if not (_fp32_split3_train and _split3_on(net)) or x.dtype != torch.float32 or not x.is_cuda or K % 128 \
+            or N not in (256, 512) \
             or int(x.shape[0]) == 0:
         return None
     # the kernel wants the weight of the Linear that maps K -> N, i.e. W[:, cols]^T  [N, K]
@@ -373,7 +390,7 @@ def _split3_linear(x: torch.Tensor, weight, cols, net) -> Optional[torch.Tensor]
 def _split3_applies(net, segments, training: bool = False) -> bool:
     """the opt-in split-bf16 path is switched on for this network and hgnn_mlp_forward_f32_split3 has its shape
     (``training``: the call comes from the differentiable forward, which dumps the pre-LayerNorm rows)"""
-    if not _split3_on(net):
+    if not _split3_on(net) or (training and not _fp32_split3_train):
         return False
     if not training and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
         return False
@@ -730,7 +747,7 @@ def _atb(A: torch.Tensor, B: torch.Tensor, net=None) -> torch.Tensor:
     8 GFLOP of n = 120k, ~110 TFLOP/s at n = 2M); a batched product over row blocks plus one sum fills the
     chip (fixed summation order: deterministic).  EC-IN training step 368 -> 306 ms."""
     n = int(A.shape[0])
-    if net is not None and _split3_on(net) and n >= 4096 and A.dtype == torch.float32 and B.dtype == torch.float32 \
+    if net is not None and _fp32_split3_train and _split3_on(net) and n >= 4096 and A.dtype == torch.float32 and B.dtype == torch.float32 \
             and A.is_cuda and int(A.shape[1]) % 8 == 0 and int(B.shape[1]) % 8 == 0:
         from .ops import wgrad_f32_split3
         stats["split3_wgrad_calls"] = stats.get("split3_wgrad_calls", 0) + 1

@@ -39,6 +39,7 @@ def _exact_fp32_matrix_arithmetic(request):
     fused.set_fp32_split3(False)
     yield
     fused.set_fp32_split3(old)
+    assert not fused._fp32_split3_train or os.environ.get("HGNN_FP32_SPLIT3_TRAIN") == "1"   # opt-in stays opt-in
 
 
 def load_golden(name):

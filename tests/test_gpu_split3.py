@@ -14,11 +14,14 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def split3():
+    """no-grad forwards AND (opt-in) the training path -- differentiable forward, backward GEMMs -- on the split-bf16 kernels"""
     from hierarchicalgnn_amd import fused
-    old = fused._fp32_split3
+    old, old_b = fused._fp32_split3, fused._fp32_split3_train
     fused.set_fp32_split3(True)
+    fused.set_fp32_split3_training(True)
     yield fused
     fused.set_fp32_split3(old)
+    fused.set_fp32_split3_training(old_b)
 
 
 @pytest.mark.parametrize("L,layers,nseg,M", [(256, 2, 3, 1), (256, 2, 3, 333), (128, 2, 3, 1000), (256, 3, 2, 200),
@@ -130,6 +133,7 @@ def test_split3_config2_training_step_gradients_within_the_bar(split3):
     assert x.requires_grad
     (scores * torch.from_numpy(z["r_scores"]).cuda()).sum().backward()
     assert split3.stats.get("split3_calls", 0) - n0 >= 2 * 2 * 14     # no-grad pass + recompute of every cell network
+    assert split3.stats.get("split3_linear_calls", 0) > 0 and split3.stats.get("split3_wgrad_calls", 0) > 0
     assert np.abs(scores.detach().cpu().numpy() - z["scores"]).max() <= C.TOL
     assert_parity(x.grad, z["grad_x"], C.TOL, "d loss / d x")
     C._sketch_close(model, z)
