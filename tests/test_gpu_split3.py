@@ -171,3 +171,23 @@ def test_split3_config3_bc_hgnn_gmm_latent256_within_the_parity_bar(split3):
     scores = C._bc_stages(model, z, process_hparams(raw), C.TOL, assert_parity)
     assert split3.stats.get("split3_calls", 0) > n0
     assert np.abs(scores.cpu().numpy() - z["bipartite_scores"]).max() <= C.TOL
+
+
+def test_split3_forward_is_graph_capturable(split3):
+    """the split-bf16 launches (weight streams cached after the warm-up, projections by library GEMMs) replay from a
+    captured HIP graph: models.GraphedInference on a small latent-128 model, replay == eager"""
+    from hierarchicalgnn_amd import synth
+    from hierarchicalgnn_amd.models import EC_InteractionGNN, GraphedInference
+    torch.manual_seed(0)
+    hp = dict(spatial_channels=3, latent=128, hidden=256, n_interaction_graph_iters=3, nb_node_layer=3,
+              nb_edge_layer=2, output_layers=3, hidden_output_activation="GELU", hidden_activation="GELU",
+              layernorm=True, share_weight=False)
+    model = EC_InteractionGNN(hp).cuda().eval()
+    x, ei = synth.trackml_event(3000, 20000, seed=3)
+    x, ei = x.cuda(), ei.cuda()
+    with torch.no_grad():
+        ref = model(x, ei)
+        n0 = split3.stats.get("split3_calls", 0)
+        g = GraphedInference(model, x, ei)
+        assert split3.stats.get("split3_calls", 0) > n0
+        assert torch.equal(g(x), ref) and torch.equal(g(x.clone()), ref)
