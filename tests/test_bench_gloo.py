@@ -90,4 +90,56 @@ def test_bench_event_sizes_and_n1_equivalence():
     assert torch.equal(a.graph, b.graph) and a.n_local == b.n_local == SIZES[0] and a.M == 2 * SIZES[1]
     assert bench.algorithmic_bytes(2_000_000, 120_000, 256) == 2_178_880_000
     args = bench.parse([])
-    assert (args.gpus, args.scaling, args.event) == (1, "weak", None)
+    assert (args.gpus, args.scaling, args.event) == (1, "both", None)
+
+
+def _run_bench(argv, env_extra=None):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(conftest.ROOT, "bench.py")] + argv, env=env,
+                       capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, [json.loads(l) for l in lines], p.stderr
+
+
+def test_bench_self_launch_bare_invocation():
+    """the driver's call `python3 bench.py --gpus N` (WORLD_SIZE unset): the parent spawns the N ranks itself, relays
+    rank 0's ONE json line and returns 0.  Rehearsed without a GPU through --selftest-launch (rendezvous, sharding and
+    halo exchange of both scaling modes on CPU tensors; nothing is measured, no aggregation runs)."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--selftest-launch"])
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["selftest"] and lines[0]["n_gpus"] == 2
+    modes = lines[0]["modes"]
+    assert set(modes) == {"weak", "strong"}
+    assert sum(modes["weak"]["rows_per_rank"]) == 2 * modes["weak"]["n_edges"]       # every directed row once
+    assert modes["weak"]["n_hits"] == 2 * modes["strong"]["n_hits"]                    # weak grows, strong is fixed
+    rc, lines, err = _run_bench(["--gpus", "3", "--selftest-launch", "--scaling", "strong", "--halo-mode", "all_to_all"])
+    assert rc == 0 and len(lines) == 1 and len(lines[0]["modes"]["strong"]["rows_per_rank"]) == 3, err
+
+
+def test_bench_self_launch_propagates_child_failure():
+    """a rank that dies must not leave the launcher waiting or returning 0: without a GPU a real (non-selftest) rank
+    exits with the 'needs an MI355X' error (the bench has no CPU fallback) and the parent returns non-zero"""
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert rc != 0 and lines == []
+    assert "needs an MI355X" in err
+
+
+def test_bench_launcher_stays_off_the_gpu():
+    """the launching parent must never initialise HIP (a process that did must not start ranks): its code path touches
+    no torch.cuda function"""
+    import ast
+    import inspect
+    for fn in (bench.launch, bench.main, bench._free_port):
+        for n in ast.walk(ast.parse(inspect.getsource(fn))):
+            assert not (isinstance(n, ast.Attribute) and n.attr in ("cuda", "hip")), fn.__name__
+            assert not (isinstance(n, ast.Name) and n.id in ("_lib", "hierarchicalgnn_amd")), fn.__name__
+    tree = ast.parse(inspect.getsource(bench.main))
+    line = {n.func.id: n.lineno for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name)}
+    assert line["launch"] < line["run_rank"]
