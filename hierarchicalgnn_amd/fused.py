@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from typing import Optional, Sequence
 
 import torch
@@ -251,29 +252,80 @@ def _fragment_order32(W: torch.Tensor) -> torch.Tensor:
     return W.view(F // 32, 32, K // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
-_wcache = {}
+class _WeightCache:
+    """prepared (re-laid-out / bf16 / split) copies of Linear weights, one per (weight object, layout).
+
+    Validity = same Parameter OBJECT (held by weak reference: a deleted model frees its entries), same storage
+    address and same in-place version counter.  ``optimizer.step()``, ``load_state_dict`` and every other in-place op
+    on the parameter bump that counter.  Writes through ``param.data`` (``p.data.normal_()``, hand-written
+    ``p.data -= lr * g``, EMA / SWA swaps) do NOT -- PyTorch gives ``.data`` a version counter of its own -- so:
+      * the Sequentials built by ``utils.make_mlp`` drop their entries in ``train()`` / ``eval()`` / ``to()`` /
+        ``load_state_dict`` (``FusedMLPSequential``), and
+      * code that edits ``.data`` between two forwards without any of these calls ``fused.clear_weight_cache()``.
+    """
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, weight, tag):
+        try:
+            ver = weight._version
+        except RuntimeError:              # inference tensors carry no version counter: never cached
+            return None
+        e = self._d.get((id(weight), tag))
+        if e is not None and e[0]() is weight and e[1] == ver and e[2] == weight.data_ptr():
+            return e[3]
+        return None
+
+    def put(self, weight, tag, value):
+        try:
+            ver = weight._version
+        except RuntimeError:
+            return
+        key = (id(weight), tag)
+        try:
+            ref = weakref.ref(weight, lambda _r, k=key, d=self._d: d.pop(k, None))
+        except TypeError:
+            return
+        self._d[key] = (ref, ver, weight.data_ptr(), value)
+
+    def drop(self, weights):
+        ids = {id(w) for w in weights}
+        for k in [k for k in self._d if k[0] in ids]:
+            self._d.pop(k, None)
+
+    def clear(self):
+        self._d.clear()
+
+    def __len__(self):
+        return len(self._d)
+
+
+_wcache = _WeightCache()
+
+
+def clear_weight_cache(module: Optional[nn.Module] = None) -> None:
+    """forget the prepared weight copies (of ``module``'s parameters, or all).  Needed only after editing weights
+    through ``param.data`` -- every in-place op on the parameter itself is detected (see ``_WeightCache``)."""
+    if module is None:
+        _wcache.clear()
+    else:
+        _wcache.drop(list(module.parameters()))
 
 
 def _prepared_weight(weight, order, kept_cols):
     """bf16 copy of a Linear weight (optionally only the column blocks of the segments that stay in the kernel's K
-    loop) in the kernel's fragment order, cached per (storage, version): an inference forward re-lays out nothing,
-    a training step once per optimizer update instead of once per call (forward + checkpoint recompute)"""
-    try:
-        ver = weight._version
-    except RuntimeError:          # inference tensors carry no version counter
-        ver = -1
-    key = (weight.data_ptr(), tuple(weight.shape), order.__name__, kept_cols)
-    hit = _wcache.get(key) if ver >= 0 else None
-    if hit is not None and hit[0] is weight and hit[1] == ver:
-        return hit[2]
+    loop) in the kernel's fragment order, cached per weight object and version: an inference forward re-lays out
+    nothing, a training step once per optimizer update instead of once per call (forward + checkpoint recompute)"""
+    tag = (order.__name__, kept_cols)
+    hit = _wcache.get(weight, tag)
+    if hit is not None:
+        return hit
     W = weight.detach()
     if kept_cols is not None:
         W = torch.cat([W[:, c0:c1] for c0, c1 in kept_cols], dim=1)
     W = order(W.to(torch.bfloat16).contiguous())
-    if ver >= 0:
-        if len(_wcache) > 4096:
-            _wcache.clear()
-        _wcache[key] = (weight, ver, W)     # one prepared copy per weight: a new version replaces the old one
+    _wcache.put(weight, tag, W)     # one prepared copy per weight and layout: a new version replaces the old one
     return W
 
 
@@ -338,15 +390,11 @@ def _split3_on(net) -> bool:
 
 def _split3_weight(weight, kept_cols, panels: bool, transpose: bool = False):
     """bf16 split stream of an fp32 Linear weight (per 32-wide k-chunk of the kept columns: W_hi, then W_mid) in
-    A-fragment order, cached per weight version"""
-    try:
-        ver = weight._version
-    except RuntimeError:
-        ver = -1
-    key = (weight.data_ptr(), tuple(weight.shape), "split3", kept_cols, panels, transpose)
-    hit = _wcache.get(key) if ver >= 0 else None
-    if hit is not None and hit[0] is weight and hit[1] == ver:
-        return hit[2]
+    A-fragment order, cached per weight object and version (``_WeightCache``)"""
+    tag = ("split3", kept_cols, panels, transpose)
+    hit = _wcache.get(weight, tag)
+    if hit is not None:
+        return hit
     W = weight.detach().float()
     if kept_cols is not None:
         W = torch.cat([W[:, c0:c1] for c0, c1 in kept_cols], dim=1)
@@ -358,10 +406,7 @@ def _split3_weight(weight, kept_cols, panels: bool, transpose: bool = False):
     # per 32-wide k-chunk: the chunk's W_hi columns, then its W_mid columns (virtual chunks 2c, 2c + 1)
     Wv = torch.stack([hi.view(F, K // 32, 32), mid.view(F, K // 32, 32)], dim=2).reshape(F, 2 * K)
     Wv = _fragment_order(Wv.contiguous())
-    if ver >= 0:
-        if len(_wcache) > 4096:
-            _wcache.clear()
-        _wcache[key] = (weight, ver, Wv)
+    _wcache.put(weight, tag, Wv)
     return Wv
 
 
@@ -764,6 +809,14 @@ def _atb(A: torch.Tensor, B: torch.Tensor, net=None) -> torch.Tensor:
     return out
 
 
+def _zero_grads(ctx, tables, params, grad_out, n_seg):
+    """backward of an MLP that was called on M == 0 rows (a shard without edges, an empty super graph): every
+    parameter and table gradient is zero; no kernel is launched"""
+    gt = [torch.zeros_like(t) if ctx.needs_input_grad[3 + i] else None for i, t in enumerate(tables)]
+    gs = [grad_out] if ctx.has_skip else []
+    return (None, None, None, *gt, *gs, *[torch.zeros_like(p) for p in params])
+
+
 class _FusedMLPTrain(torch.autograd.Function):
     """Differentiable fused MLP.  Forward = the same MFMA kernel, additionally dumping each layer's
     pre-LayerNorm output z_l (``save_pre``).  Backward is written out by hand: LayerNorm / activation
@@ -825,6 +878,8 @@ class _FusedMLPTrain(torch.autograd.Function):
         tables = saved[:n_seg]
         params = saved[n_seg:n_seg + 4 * n]
         zs = saved[n_seg + 4 * n:]
+        if int(grad_out.shape[0]) == 0:
+            return _zero_grads(ctx, tables, params, grad_out, n_seg)
         W = [params[4 * l] for l in range(n)]
         lw = [lin.weight for lin, _, _ in _parse(ctx.net)]   # the Parameter objects themselves (weight-prep cache keys)
         lnw = [params[4 * l + 2] for l in range(n)]
@@ -1083,6 +1138,8 @@ class _FusedMLPTrainBf16(torch.autograd.Function):
         tables = saved[:n_seg]
         params = saved[n_seg:n_seg + 4 * n]
         zs = saved[n_seg + 4 * n:]
+        if int(grad_out.shape[0]) == 0:
+            return _zero_grads(ctx, tables, params, grad_out, n_seg)
         W = [params[4 * l] for l in range(n)]
         lnw = [params[4 * l + 2] for l in range(n)]
         lnb = [params[4 * l + 3] for l in range(n)]

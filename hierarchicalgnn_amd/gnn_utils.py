@@ -26,6 +26,7 @@ from torch.utils.checkpoint import checkpoint
 
 from .mlp import concat_mlp
 from .ops import gather_scale_scatter, scatter_add
+from .plan import stable_index
 from .utils import make_mlp
 
 
@@ -66,6 +67,7 @@ class InteractionGNNCell(nn.Module):
 
     # gnn_utils.py:66-71 -- the edge update sees the UPDATED nodes
     def forward(self, nodes, edges, graph):
+        graph = stable_index(graph)          # inference-tensor graphs: one normal clone per call keys the caches
         nodes = self.node_update(nodes, edges, graph)
         edges = self.edge_update(nodes, edges, graph)
         return nodes, edges
@@ -143,6 +145,7 @@ class HierarchicalGNNCell(nn.Module):
     # gnn_utils.py:155-169 : supernode -> node -> superedge -> edge
     def forward(self, nodes, edges, supernodes, superedges, graph, bipartite_graph, bipartite_edge_weights,
                 super_graph, super_edge_weights):
+        graph, bipartite_graph, super_graph = (stable_index(g) for g in (graph, bipartite_graph, super_graph))
         supernodes = self.supernode_update(nodes, supernodes, superedges, bipartite_graph,
                                            bipartite_edge_weights, super_graph, super_edge_weights)
         nodes = self.node_update(nodes, edges, supernodes, graph, bipartite_graph, bipartite_edge_weights)

@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from .gnn_utils import InteractionGNNCell, _maybe_checkpoint
 from .mlp import concat_mlp
-from .plan import memo
+from .plan import memo, stable_index
 from .utils import make_mlp, process_hparams
 
 
@@ -105,6 +105,7 @@ class InteractionGNNBlock(nn.Module):
         # each node's incoming edge rows as ONE contiguous HBM stream instead of gathering 1-KiB
         # rows by edge id; the original order (which IN.py:126 relies on) is restored once at the end.
         order = None
+        graph = stable_index(graph)
         graph_in = graph
         if self.hparams.get("sort_edges", True) and graph.is_cuda and graph.shape[1] > 0:
             order, graph, inverse = memo(graph, "dst_sorted", lambda g=graph: _dst_sorted(g))
@@ -147,6 +148,7 @@ class EC_InteractionGNN(nn.Module):
         _mark_split3(self, hparams)
 
     def forward(self, x, graph):
+        graph = stable_index(graph)
         directed_graph = memo(graph, "directed", lambda: torch.cat([graph, graph.flip(0)], dim=1))  # IN.py:122
         nodes, edges = self.ignn_block(x, directed_graph)
         edges = _head_input(edges, self.hparams)
@@ -240,6 +242,7 @@ class HierarchicalGNNBlock(nn.Module):
     def forward(self, nodes, edges, graph, means, bipartite_graph, bipartite_edge_weights, super_graph,
                 super_edge_weights):
         from .ops import gather_scale_scatter, l1_row_scale
+        graph, bipartite_graph, super_graph = (stable_index(g) for g in (graph, bipartite_graph, super_graph))
         # HGNN_GMM.py:269 -- L1-normalised rows, weighted, summed per supernode (K5, one fused kernel)
         pooled = gather_scale_scatter(nodes, bipartite_graph[0], bipartite_graph[1], means.shape[0],
                                       bipartite_edge_weights, row_scale=l1_row_scale(nodes))
@@ -277,6 +280,7 @@ class BC_MessagePassing(nn.Module):
         (``order`` = sorted position -> column of cat([graph, graph.flip(0)])): the BC model only
         returns node-level quantities, so the HGNN block keeps streaming on that layout and the
         un-permute is never paid."""
+        graph = stable_index(graph)
         directed_graph = memo(graph, "directed", lambda: torch.cat([graph, graph.flip(0)], dim=1))
         emb, nodes, edges, directed_graph, order = self.ignn_block.run(x, directed_graph, restore_order)
         return directed_graph, emb, nodes, edges, order
@@ -315,7 +319,7 @@ class GraphedInference:
     def __init__(self, model, x, edge_index, warmup: int = 2):
         self.model = model
         self.x = x.clone()
-        self.edge_index = edge_index
+        self.edge_index = stable_index(edge_index)      # an inference-tensor graph would be re-cloned (and re-planned) per call
         stream = torch.cuda.Stream(x.device)
         stream.wait_stream(torch.cuda.current_stream(x.device))
         with torch.no_grad(), torch.cuda.stream(stream):

@@ -123,19 +123,40 @@ class GraphPlan:
                     err=c[_lib.CNT_ERR], valid=c[_lib.CNT_VALID])
 
 
+_UNCACHEABLE = object()
+
+
 def _key(t: Optional[torch.Tensor]):
     if t is None:
         return None
-    # inference tensors (created under torch.inference_mode(), as the reference runs its models) do
-    # not track a version counter -- and cannot be edited in place outside inference mode either
-    version = 0 if t.is_inference() else t._version
-    return (t.data_ptr(), version, tuple(t.shape), tuple(t.stride()), t.device.index)
+    # inference tensors (created under torch.inference_mode()) track no version counter, yet CAN be edited in place
+    # inside inference mode (a reused static ``edge_index`` buffer refilled with ``copy_``): nothing tells two events
+    # apart, so nothing derived from such a tensor is ever cached (``stable_index`` gives callers that loop over many
+    # aggregations of one event a normal clone to key on)
+    if t.is_inference():
+        return _UNCACHEABLE
+    return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.device.index)
+
+
+def stable_index(t: torch.Tensor) -> torch.Tensor:
+    """the tensor itself, or -- for an inference tensor -- a NORMAL clone of its current contents.  The cells and
+    models call this once per forward on the caller's graph: every plan / int32 copy / derived tensor of that forward
+    is then keyed on the clone (cache hits across the 14 / 6 + 6 aggregations of the event), and a later in-place
+    refill of the caller's buffer yields a new clone, hence new plans."""
+    if torch.is_tensor(t) and t.is_inference():
+        with torch.inference_mode(False):
+            return t.clone()
+    return t
 
 
 def get_plan(dst_index: torch.Tensor, dim_size: int, gather_index: Optional[torch.Tensor] = None,
              n_src: Optional[int] = None, validate: bool = True) -> GraphPlan:
     """cached GraphPlan for (dst_index, dim_size[, gather_index, n_src])"""
     key = (_key(dst_index), int(dim_size), _key(gather_index), None if n_src is None else int(n_src))
+    if key[0] is _UNCACHEABLE or key[2] is _UNCACHEABLE:
+        with torch.inference_mode(False):
+            return GraphPlan(stable_index(dst_index), dim_size,
+                             None if gather_index is None else stable_index(gather_index), n_src, validate=validate)
     hit = _CACHE.get(key)
     if hit is not None:
         _CACHE.move_to_end(key)
@@ -172,12 +193,13 @@ def get_index32(index: torch.Tensor, limit: int) -> torch.Tensor:
     if not index.is_cuda or index.dtype != torch.int64 or index.dim() != 1:
         raise RuntimeError("get_index32: index must be a 1-D int64 HIP tensor")
     key = (_key(index), int(limit))
-    hit = _IDX_CACHE.get(key)
+    cacheable = key[0] is not _UNCACHEABLE
+    hit = _IDX_CACHE.get(key) if cacheable else None
     if hit is not None:
         _IDX_CACHE.move_to_end(key)
         return hit[0]
     # reuse a destination plan's dst32 if one exists for this index (same contents)
-    for (k_dst, k_n, k_g, _), (plan, _, _) in _CACHE.items():
+    for (k_dst, k_n, k_g, _), (plan, _, _) in (_CACHE.items() if cacheable else ()):
         if k_dst == key[0] and k_g is None and k_n == int(limit):
             out = plan.dst32[:index.numel()] if index.numel() else plan.dst32[:0]
             _IDX_CACHE[key] = (out, index)
@@ -194,6 +216,8 @@ def get_index32(index: torch.Tensor, limit: int) -> torch.Tensor:
     if int(err.item()) != 0:
         raise RuntimeError(f"gather index out of range for a table of {limit} rows")
     out = out[:M]
+    if not cacheable:
+        return out
     _IDX_CACHE[key] = (out, index)
     while len(_IDX_CACHE) > _CACHE_SIZE:
         _IDX_CACHE.popitem(last=False)
@@ -210,6 +234,9 @@ def memo(index: torch.Tensor, tag: str, make):
     Handing back the SAME derived tensors on every call is what lets their plans hit the cache above
     -- and what makes a whole forward capturable into a HIP graph (no sort, no plan build on replay)."""
     key = (_key(index), tag)
+    if key[0] is _UNCACHEABLE:
+        with torch.inference_mode(False):
+            return make()
     hit = _MEMO.get(key)
     if hit is not None:
         _MEMO.move_to_end(key)

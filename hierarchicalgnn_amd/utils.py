@@ -12,6 +12,34 @@ from __future__ import annotations
 import torch.nn as nn
 
 
+class FusedMLPSequential(nn.Sequential):
+    """``nn.Sequential`` (same sub-module indices, same ``state_dict`` keys) that forgets the fused kernels' prepared
+    copies of its weights whenever the module is switched / moved / reloaded: ``train()``, ``eval()``, ``to()`` /
+    ``cuda()`` / ``float()`` (``_apply``) and ``load_state_dict``.  In-place ops on the parameters themselves are
+    caught by their version counters; these hooks cover edits through ``param.data`` that are followed by one of
+    the calls above (``fused._WeightCache``)."""
+
+    def _drop_prepared(self):
+        from . import fused
+        fused.clear_weight_cache(self)
+
+    def train(self, mode: bool = True):
+        self._drop_prepared()
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._drop_prepared()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._drop_prepared()
+        return super().load_state_dict(*a, **k)
+
+    def _load_from_state_dict(self, *a, **k):       # reached when a PARENT module's load_state_dict recurses
+        self._drop_prepared()
+        return super()._load_from_state_dict(*a, **k)
+
+
 def make_mlp(input_size, hidden_size, output_size, hidden_layers, hidden_activation="GELU",
              output_activation="GELU", layer_norm=False):
     """[Linear -> (LayerNorm) -> act] x (hidden_layers-1) -> Linear -> (LayerNorm -> act)"""
@@ -29,7 +57,7 @@ def make_mlp(input_size, hidden_size, output_size, hidden_layers, hidden_activat
         if layer_norm:
             layers.append(nn.LayerNorm(sizes[-1]))
         layers.append(out_act())
-    return nn.Sequential(*layers)
+    return FusedMLPSequential(*layers)
 
 
 def process_hparams(hparams):

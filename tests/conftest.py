@@ -13,6 +13,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "both_fp32_gemms(must_run=True): model-level GPU test, run once per fp32 GEMM "
+                                       "kernel (exact fp32 MFMA / split-bf16 default)")
 
 
 def pytest_sessionstart(session):
@@ -24,22 +26,37 @@ def pytest_sessionstart(session):
         b.build(verbose=False)
 
 
+def pytest_generate_tests(metafunc):
+    """Model-level GPU tests (``@pytest.mark.both_fp32_gemms``) run TWICE in the driver's single ``pytest -m gpu``:
+    once on the exact fp32 matrix instruction and once on the shipped process default (split-bf16 GEMMs for no-grad
+    fp32 MLPs at latent 128 / 256, fused.set_fp32_split3) -- every model-level 1e-4 bar certifies both kernels."""
+    if metafunc.definition.get_closest_marker("both_fp32_gemms") is not None:
+        metafunc.fixturenames.append("fp32_gemm")
+        metafunc.parametrize("fp32_gemm", ["exact", "split_bf16"])
+
+
 @pytest.fixture(autouse=True)
-def _exact_fp32_matrix_arithmetic(request):
-    """The process default evaluates the fp32 MLPs' GEMMs as split-bf16 products (fused.set_fp32_split3, <= 1.6e-5 vs
-    the reference); the GPU parity tests pin the EXACT fp32 kernels unless they are the split-bf16 tests themselves
-    (tests/test_gpu_split3.py), so that both kernels stay covered.  The whole suite also passes with the default left
-    on (HGNN_KEEP_DEFAULT_FP32_GEMM=1 python -m pytest -m gpu; profiles/r02_gpu_suite_split3_on.txt)."""
-    if "gpu" not in request.keywords or request.module.__name__ == "test_gpu_split3" \
-            or os.environ.get("HGNN_KEEP_DEFAULT_FP32_GEMM") == "1":
+def _fp32_matrix_arithmetic(request):
+    """Which kernel evaluates the fp32 MLPs' GEMMs in a GPU test:
+      * tests marked ``both_fp32_gemms`` are parametrised over ``fp32_gemm`` in {exact, split_bf16} (above);
+      * tests/test_gpu_split3.py manages the switch itself;
+      * every other GPU test pins the EXACT fp32 kernels (kernel-level parity of the fp32 MFMA path).
+    The process default (what ships) is split_bf16; it is restored afterwards."""
+    if "gpu" not in request.keywords or request.module.__name__ == "test_gpu_split3":
         yield
         return
     from hierarchicalgnn_amd import fused
+    mode = "exact"
+    callspec = getattr(request.node, "callspec", None)
+    if callspec is not None:
+        mode = callspec.params.get("fp32_gemm", "exact")
     old = fused._fp32_split3
-    fused.set_fp32_split3(False)
+    fused.set_fp32_split3(mode == "split_bf16")
+    n0 = fused.stats.get("split3_calls", 0)
     yield
+    if mode == "split_bf16" and request.node.get_closest_marker("both_fp32_gemms").kwargs.get("must_run", True):
+        assert fused.stats.get("split3_calls", 0) > n0, "split_bf16 variant: the split-bf16 kernel never ran"
     fused.set_fp32_split3(old)
-    assert not fused._fp32_split3_train or os.environ.get("HGNN_FP32_SPLIT3_TRAIN") == "1"   # opt-in stays opt-in
 
 
 def load_golden(name):

@@ -130,6 +130,26 @@ def test_fused_train_bf16_matches_fp32_autograd(L, layers):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= BF16_GRAD, name
 
 
+@pytest.mark.parametrize("bf16", [True, False])
+def test_fused_train_on_zero_rows(bf16):
+    """M == 0 (a shard without edges, an empty super graph): forward returns [0, L], backward returns zero parameter
+    and table gradients without launching anything (the bf16 backward used to reject its own NULL dumps)"""
+    from hierarchicalgnn_amd import fused, mlp
+    L = 128
+    net = _net(3 * L, L, 2, "Tanh", L).cuda()
+    dt = torch.bfloat16 if bf16 else torch.float32
+    table = torch.randn(50, L, device="cuda").to(dt).requires_grad_(True)
+    idx = torch.zeros(0, dtype=torch.long, device="cuda")
+    direct = torch.zeros(0, L, device="cuda", dtype=dt, requires_grad=True)
+    n0 = fused.stats["fused_train_calls"]
+    out = mlp.concat_mlp(net, [(table, idx), (table, idx), (direct, None)], skip=direct)
+    assert fused.stats["fused_train_calls"] == n0 + 1 and tuple(out.shape) == (0, L)
+    out.float().sum().backward()
+    assert table.grad is not None and float(table.grad.abs().max()) == 0.0 and tuple(direct.grad.shape) == (0, L)
+    for p in net.parameters():
+        assert p.grad is not None and float(p.grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("ckpt", [True, False])
 def test_interaction_cell_bf16_training_against_the_fp32_golden_gradients(ckpt):
     """config 4's dtype through a whole cell at latent 128: the REFERENCE's fp32 outputs and gradients

@@ -24,6 +24,7 @@ def _load(cell, z, prefix="sd."):
     return cell.cuda()
 
 
+@pytest.mark.both_fp32_gemms(must_run=False)
 @pytest.mark.parametrize("latent,ckpt", [(32, True), (32, False), (128, True)])
 def test_interaction_cell(latent, ckpt):
     import hierarchicalgnn_amd as H

@@ -53,6 +53,7 @@ def _sketch_close(model, z, tol=TOL):
         assert abs(got[i, 2] - ref[i, 2]) <= slack, (n, got[i], ref[i])
 
 
+@pytest.mark.both_fp32_gemms
 def test_config2_ec_in_latent128_forward_and_backward():
     from hierarchicalgnn_amd import fused
     from hierarchicalgnn_amd.models import EC_InteractionGNN
@@ -78,6 +79,7 @@ def test_config2_ec_in_latent128_forward_and_backward():
     _sketch_close(model, z)
 
 
+@pytest.mark.both_fp32_gemms
 def test_config3_hgnn_cell_latent256_forward_and_backward():
     import hierarchicalgnn_amd as H
     z = load_golden("hgnn_cell_L256.npz")
@@ -130,6 +132,7 @@ def _bc_stages(model, z, hp, tol, check):
     return scores
 
 
+@pytest.mark.both_fp32_gemms(must_run=False)
 @pytest.mark.parametrize("latent", [256, 512])
 def test_config3_bc_hgnn_gmm_fp32(latent):
     """latent 256 = HGNN_GMM.yaml as shipped (config 3); latent 512 = the fp32 arithmetic of config 4"""
@@ -167,6 +170,7 @@ def test_config4_bc_hgnn_gmm_latent512_bf16_mode():
 
 
 # ----------------------------------------------------------------------------------------------- full sizes
+@pytest.mark.both_fp32_gemms
 def test_config2_full_size_ec_in_forward_properties():
     """EC-IN latent 128 on the BASELINE event (N = 120k, E = 1M): finite scores in (0, 1), every MLP on the
     fused kernel, and invariance under a permutation of the stored edge order (the model sorts internally;

@@ -356,6 +356,7 @@ def test_fused_embedding_head(L, emb, act):
     assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
 
 
+@pytest.mark.both_fp32_gemms
 def test_bc_forward_latent256_has_no_library_mlp():
     """f2: every MLP of a BC-HGNN-GMM inference forward at the shipped config (latent 256) runs on the fused
     kernel -- encoders (node, edge, supernode, superedge), 6 + 6 cells, embedding head, bipartite head; none

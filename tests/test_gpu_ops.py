@@ -411,3 +411,36 @@ def test_grouped_narrow_row_kernel_option(H, O):
             assert rel_err(out.cpu().numpy(), O.scatter_add(tab[gi] * w, idx, 0, N).numpy()) <= 1e-5, F
     finally:
         _lib.check(lib.hgnn_set_option(b"seg_grouped", 0))
+
+
+def test_inference_tensor_index_refilled_in_place_is_never_served_from_a_cache(H):
+    """an index created under torch.inference_mode() has no version counter but CAN be overwritten in place there (a
+    static edge_index buffer refilled per event): plans / int32 copies / derived tensors must follow the contents"""
+    from hierarchicalgnn_amd import plan as P
+    from hierarchicalgnn_amd.gnn_utils import InteractionGNNCell
+    torch.manual_seed(3)
+    N, M, L = 300, 2000, 32
+    cell = InteractionGNNCell(dict(latent=L, hidden=2 * L, nb_edge_layer=2, nb_node_layer=3, layernorm=True,
+                                   hidden_activation="GELU")).cuda().eval()
+    with torch.inference_mode():
+        g1 = torch.randint(0, N, (2, M), device="cuda")
+        g2 = torch.randint(0, N, (2, M), device="cuda")
+        buf = g1.clone()
+        assert buf.is_inference()
+        src = torch.randn(M, L, device="cuda")
+        nodes = torch.randn(N, L, device="cuda")
+        a1 = H.scatter_add(src, buf[1], dim=0, dim_size=N)
+        n1, e1 = cell(nodes, src, buf)
+        buf.copy_(g2)                                        # same storage, same shape, new event
+        a2 = H.scatter_add(src, buf[1], dim=0, dim_size=N)
+        n2, e2 = cell(nodes, src, buf)
+        r1 = torch.zeros(N, L, device="cuda").index_add_(0, g1[1], src)
+        r2 = torch.zeros(N, L, device="cuda").index_add_(0, g2[1], src)
+        assert float((a1 - r1).abs().max()) < 1e-4 and float((a2 - r2).abs().max()) < 1e-4
+        m1, f1 = cell(nodes, src, g1.clone())
+        m2, f2 = cell(nodes, src, g2.clone())
+        assert torch.equal(n1, m1) and torch.equal(e1, f1) and torch.equal(n2, m2) and torch.equal(e2, f2)
+        assert not torch.equal(e1, e2)
+    assert P.stable_index(g1) is not g1 and not P.stable_index(g1).is_inference()
+    k = torch.randint(0, N, (M,), device="cuda")
+    assert P.stable_index(k) is k

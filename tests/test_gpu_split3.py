@@ -191,3 +191,122 @@ def test_split3_forward_is_graph_capturable(split3):
         g = GraphedInference(model, x, ei)
         assert split3.stats.get("split3_calls", 0) > n0
         assert torch.equal(g(x), ref) and torch.equal(g(x.clone()), ref)
+
+
+def test_prepared_weight_cache_follows_weight_edits(split3):
+    """The split-bf16 / bf16 kernels read PREPARED copies of the Linear weights (fused._WeightCache).  Every way a
+    weight can change must reach the kernel: in-place ops on the parameter (version counter), ``.data`` edits
+    followed by eval() / train() / to() / load_state_dict (FusedMLPSequential hooks), and ``.data`` edits followed
+    by the explicit ``fused.clear_weight_cache()``; a deleted model must free its entries."""
+    import gc
+    from hierarchicalgnn_amd import make_mlp
+    torch.manual_seed(5)
+    L, M = 128, 500
+    net = make_mlp(L, 2 * L, L, 2, layer_norm=True, output_activation="Tanh", hidden_activation="GELU").cuda()
+    x = torch.randn(M, L, device="cuda")
+
+    def run():
+        with torch.no_grad():
+            return split3.fused_concat_mlp(net, [(x, None)], None).clone()
+
+    def ref():
+        with torch.no_grad():
+            return net(x)
+
+    base = run()
+    assert float((base - ref()).abs().max()) < 1e-4 and len(split3._wcache) >= 2
+    with torch.no_grad():
+        net[0].weight.normal_(0, 0.05)                       # in-place on the parameter: version counter
+    a = run()
+    assert float((a - ref()).abs().max()) < 1e-4 and float((a - base).abs().max()) > 1e-2
+    net[0].weight.data.normal_(0, 0.05)                      # through .data: invisible to the version counter ...
+    net.eval()                                               # ... dropped by the module hook
+    b = run()
+    assert float((b - ref()).abs().max()) < 1e-4 and float((b - a).abs().max()) > 1e-2
+    net[3].weight.data.mul_(0.5)
+    split3.clear_weight_cache(net)                           # ... or by the explicit call
+    c = run()
+    assert float((c - ref()).abs().max()) < 1e-4 and float((c - b).abs().max()) > 1e-3
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd["0.weight"] = sd["0.weight"] * 1.5
+    torch.nn.ModuleDict({"n": net}).load_state_dict({"n." + k: v for k, v in sd.items()})   # through a parent
+    d = run()
+    assert float((d - ref()).abs().max()) < 1e-4 and float((d - c).abs().max()) > 1e-3
+    n_before = len(split3._wcache)
+    del net
+    gc.collect()
+    assert len(split3._wcache) <= n_before - 2               # weak references: the entries died with the model
+
+
+# ----------------------------------------------------------------------------------------------- full-size A/B
+AB_BOUND = 5e-5      # stated bound for |scores_split - scores_exact| at the sizes the numbers are quoted on
+
+
+def _both_modes(fn):
+    from hierarchicalgnn_amd import fused
+    old = fused._fp32_split3
+    out = {}
+    try:
+        for name, flag in (("exact", False), ("split", True)):
+            fused.set_fp32_split3(flag)
+            n0 = fused.stats.get("split3_calls", 0)
+            with torch.inference_mode():
+                out[name] = fn()
+            ran = fused.stats.get("split3_calls", 0) - n0
+            assert (ran > 0) == flag, (name, ran)
+    finally:
+        fused.set_fp32_split3(old)
+    return out["exact"], out["split"]
+
+
+def test_full_size_ab_ec_in_latent128_split_vs_exact():
+    """config 2's model on the BASELINE event (N = 120k hits, E = 1M edges; the reference fixtures are 540-1,500
+    hits): the shipped default (split-bf16 GEMMs) against the exact fp32 kernels, same weights, same event"""
+    from hierarchicalgnn_amd import synth
+    from hierarchicalgnn_amd.models import EC_InteractionGNN
+    from golden import seeded
+    model = EC_InteractionGNN(C._cfg("EC-IN"))
+    seeded.fill_parameters(model, 7)
+    model = model.cuda().eval()
+    x, ei = synth.trackml_event(120_000, 1_000_000, seed=1234)
+    x, ei = x.cuda(), ei.cuda()
+    s_exact, s_split = _both_modes(lambda: model(x, ei).clone())
+    d = (s_split - s_exact).abs()
+    assert s_exact.shape == (1_000_000,) and float(s_exact.std()) > 1e-3
+    assert float(d.max()) <= AB_BOUND, float(d.max())
+
+
+def test_full_size_ab_bc_latent256_split_vs_exact():
+    """config 3's model (latent 256, 6 + 6 cells) on the BASELINE event with a fixed synthetic hierarchy decision
+    (phi-z cells; the kNN topology is taken from the exact run so that a tie cannot change the graphs between the two
+    arms): embeddings, node / supernode latents and bipartite scores of the split-bf16 default against exact fp32"""
+    from hierarchicalgnn_amd import synth
+    from hierarchicalgnn_amd.models import BC_MessagePassing
+    from golden import seeded
+    model = BC_MessagePassing(C._cfg("BC-HGNN-GMM"))
+    seeded.fill_parameters(model, 7)
+    model = model.cuda().eval()
+    model.hgnn_block.super_graph_construction.knn_radius.fill_(2.0)
+    model.hgnn_block.bipartite_graph_construction.knn_radius.fill_(2.0)
+    x, ei = synth.trackml_event(120_000, 1_000_000, seed=1234)
+    x, ei = x.cuda(), ei.cuda()
+    cl = ((x[:, 1] + 1) * 50).long().clamp(0, 99) * 100 + ((x[:, 2] + 1) * 50).long().clamp(0, 99)
+    _, clusters = torch.unique(cl, return_inverse=True)
+    n_cl = int(clusters.max()) + 1
+    graphs = {}
+
+    def forward():
+        directed, emb, nodes, edges, _ = model.embed(x, ei)
+        if not graphs:
+            _, bg, _, sg, _, _ = model.hgnn_block.hierarchy_from_clusters(emb, clusters, n_cl)
+            graphs["g"] = (bg, sg)
+        means, bg, bw, sg, sw, _ = model.hgnn_block.hierarchy_from_clusters(emb, clusters, n_cl, graphs=graphs["g"])
+        n_out, sn_out, _, _ = model.hgnn_block(nodes, edges, directed, means, bg, bw, sg, sw)
+        return emb.clone(), n_out.clone(), sn_out.clone(), model.score(n_out, sn_out, bg).clone()
+
+    exact, split = _both_modes(forward)
+    for a, b, what in zip(split[:3], exact[:3], ("embeddings", "nodes", "supernodes")):
+        assert_parity(a, b, 1e-4, what + " (split vs exact, full size)")
+    d = (split[3] - exact[3]).abs()
+    assert float(exact[3].std()) > 1e-3
+    assert float(d.max()) <= AB_BOUND, float(d.max())
