@@ -649,6 +649,84 @@ def gen_bc_hgnn_config(BC, latent, configs=None):
           bg.shape[1], "super edges", first[7].shape[1])
 
 
+def gen_bc_hgnn_backward(BC, latent=256, c_emb=0.1):
+    """BASELINE config 3 TRAINS (bipartite_classification_base.py:194-200 calls the forward of HGNN_GMM.py:323-346 in
+    training mode and back-propagates through it): the reference's own BC_HierarchicalGNN_GMM built from HGNN_GMM.yaml,
+    in train() mode, forward WITH autograd and backward of the surrogate loss
+
+        loss = (bipartite_scores * r).sum() + c_emb * (emb * emb.roll(1, 0)).sum()
+
+    (the reference's hinge / matching losses are host-side scipy code outside the hot path; a loss linear in the
+    scores plus a bilinear form of the embeddings sends a generic gradient through both outputs).  The discrete
+    hierarchy decision is captured so that a replay can inject it: cluster label per hit, bipartite and super graph
+    topology.  Stored gradients: d loss / d x, the (sum, |.|-sum, probe) sketch of EVERY parameter gradient, the full
+    gradient of two wide weights and d loss / d bipartite_edge_weights."""
+    _, hp = ref_config("BipartiteClassification/Configs/HGNN_GMM.yaml")
+    if latent != hp["latent"]:
+        hp["latent"] = latent
+        hp["hidden"] = hp["hidden_ratio"] * latent
+    seed = 1000 + latent
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    model = BC(hp)
+    seeded.fill_parameters(model, seed)
+    model.train()
+    hb = model.hgnn_block
+    hb.super_graph_construction.knn_radius.fill_(2.0)
+    hb.bipartite_graph_construction.knn_radius.fill_(2.0)
+    g = torch.Generator().manual_seed(seed + 1)
+    x, graph = synth_tracks(60, 9, g)
+    cap = {}
+    real_clustering = hb.clustering
+
+    def clustering(xx, emb, gr):
+        cl = real_clustering(xx, emb, gr)
+        cap["clusters"] = cl.detach().clone()
+        return cl
+
+    hb.clustering = clustering
+
+    def bip_hook(m, inp, out):
+        cap["bg"], cap["bw"] = out[0].detach().clone(), out[1]
+        out[1].retain_grad()
+
+    def sup_hook(m, inp, out):
+        cap["sg"], cap["sw"] = out[0].detach().clone(), out[1]
+        out[1].retain_grad()
+
+    hb.bipartite_graph_construction.register_forward_hook(bip_hook)
+    hb.super_graph_construction.register_forward_hook(sup_hook)
+    x = x.clone()
+    bg, scores, emb = model(x, graph)          # sets x.requires_grad itself (HGNN_GMM.py:326)
+    emb.retain_grad()
+    r = seeded.randn(seed, "r_scores", scores.shape[0])
+    loss = (scores * r).sum() + c_emb * (emb * emb.roll(1, 0)).sum()
+    loss.backward()
+    assert torch.equal(bg, cap["bg"])
+    n_params = sum(p.numel() for p in model.parameters())
+    named = [(n, p) for n, p in model.named_parameters()]
+    no_grad = [n for n, p in named if p.grad is None]
+    params = dict(named)
+    d = dict(x=x.detach().numpy(), edge_index=graph.numpy(), clusters=cap["clusters"].numpy(),
+             n_clusters=np.int64(int(cap["clusters"].max()) + 1), bipartite_graph=cap["bg"].numpy(),
+             super_graph=cap["sg"].numpy(), bipartite_edge_weights=cap["bw"].detach().numpy(),
+             super_edge_weights=cap["sw"].detach().numpy(), bipartite_scores=scores.detach().numpy(),
+             embeddings=emb.detach().numpy(), r_scores=r.numpy(), c_emb=np.float64(c_emb), loss=np.float64(float(loss)),
+             grad_x=x.grad.numpy(), grad_embeddings=emb.grad.numpy(),
+             grad_bipartite_edge_weights=cap["bw"].grad.numpy(), grad_super_edge_weights=cap["sw"].grad.numpy(),
+             n_params=np.int64(n_params), seed=np.int64(seed), latent=np.int64(latent),
+             param_checksums=seeded.checksums(model.named_parameters()),
+             grad_sketch=seeded.grad_sketch((n, p.grad if p.grad is not None else torch.zeros_like(p))
+                                            for n, p in named),
+             params_without_grad=np.array(no_grad if no_grad else [""]))
+    for k in ("ignn_block.ignn_cells.0.edge_network.0.weight", "hgnn_block.hgnn_cells.5.supernode_network.3.weight",
+              "hgnn_block.bipartite_graph_construction.weight_normalization.weight", "bipartite_output_layer.0.weight"):
+        d["grad." + k] = params[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, f"bc_hgnn_train_L{latent}.npz"), **d)
+    print(f"bc_hgnn_train_L{latent}.npz params", n_params, "clusters", int(d["n_clusters"]), "bipartite edges",
+          cap["bg"].shape[1], "super edges", cap["sg"].shape[1], "loss", float(loss), "params without grad", no_grad)
+
+
 def gen_large(gnn_utils, EC, BC):
     import json
     configs = gen_ref_configs()
@@ -656,6 +734,7 @@ def gen_large(gnn_utils, EC, BC):
     gen_hgnn_cell_seeded(gnn_utils, 256)
     gen_bc_hgnn_config(BC, 256, configs)
     gen_bc_hgnn_config(BC, 512)
+    gen_bc_hgnn_backward(BC, 256)
     with open(os.path.join(OUT, "ref_configs.json"), "w") as f:
         json.dump(configs, f, indent=1, sort_keys=True)
     print("ref_configs.json")
@@ -665,6 +744,9 @@ if __name__ == "__main__":
     gnn_utils, utils, EC, BC = _import_reference()
     if "--only-dataset" in sys.argv:
         gen_dataset(utils)
+        sys.exit(0)
+    if "--only-bc-backward" in sys.argv:
+        gen_bc_hgnn_backward(BC, 256)
         sys.exit(0)
     if "--only-large" in sys.argv:
         gen_large(gnn_utils, EC, BC)

@@ -41,7 +41,8 @@ def _sketch_close(model, z, tol=TOL):
     eps * abssum / sqrt(n): both are held to eps = tol (x5 for the random-walk constant)."""
     names = sorted(n for n, _ in model.named_parameters())
     params = dict(model.named_parameters())
-    got = seeded.grad_sketch((n, params[n].grad) for n in names)
+    got = seeded.grad_sketch((n, params[n].grad if params[n].grad is not None else torch.zeros_like(params[n]))
+                             for n in names)
     ref = z["grad_sketch"]
     assert got.shape == ref.shape
     for i, n in enumerate(names):
@@ -144,6 +145,51 @@ def test_config3_bc_hgnn_gmm_fp32(latent):
     assert sum(p.numel() for p in model.parameters()) == int(z["n_params"])
     scores = _bc_stages(model, z, process_hparams(raw), TOL, assert_parity)
     assert np.abs(scores.cpu().numpy() - z["bipartite_scores"]).max() <= TOL
+
+
+@pytest.mark.both_fp32_gemms
+def test_config3_bc_training_step_against_the_reference_gradients():
+    """config 3 TRAINS: the reference's own BC_HierarchicalGNN_GMM (HGNN_GMM.yaml, latent 256, 25,299,957 parameters)
+    in train() mode, forward with autograd + backward of  (scores * r).sum() + c * (emb * emb.roll(1, 0)).sum()
+    (bipartite_classification_base.py:194-200 -> HGNN_GMM.py:323-346; fixture: make_golden.gen_bc_hgnn_backward).
+    The HIP path replays it through BC_MessagePassing.embed -> hierarchy_from_clusters (the captured discrete
+    decision: cluster labels, kNN topologies) -> hgnn_block -> score, in training mode (batch-statistics BatchNorm,
+    reentrant checkpointing), and is held to the reference's gradients at 1e-4, normwise and element-wise."""
+    from hierarchicalgnn_amd import fused
+    from hierarchicalgnn_amd.models import BC_MessagePassing
+    z = load_golden("bc_hgnn_train_L256.npz")
+    model = _seeded(BC_MessagePassing, _cfg("BC-HGNN-GMM"), z).train()
+    assert sum(p.numel() for p in model.parameters()) == int(z["n_params"]) == 25299957
+    t = lambda k: torch.from_numpy(z[k]).cuda()
+    x, graph = t("x"), t("edge_index")
+    n0 = fused.stats["fused_train_calls"]
+    directed, emb, nodes, edges, _ = model.embed(x, graph)
+    assert x.requires_grad                                           # HGNN_GMM.py:326 sets it on the caller's leaf
+    emb.retain_grad()
+    means, bg, bw, sg, sw, _ = model.hgnn_block.hierarchy_from_clusters(
+        emb, t("clusters"), int(z["n_clusters"]), graphs=(t("bipartite_graph"), t("super_graph")))
+    bw.retain_grad()
+    sw.retain_grad()
+    assert_parity(emb, z["embeddings"], TOL, "embeddings")
+    assert_parity(bw, z["bipartite_edge_weights"], TOL, "bipartite edge weights (training-mode BatchNorm)")
+    assert_parity(sw, z["super_edge_weights"], TOL, "super edge weights")
+    n_out, sn_out, _, _ = model.hgnn_block(nodes, edges, directed, means, bg, bw, sg, sw)
+    scores = model.score(n_out, sn_out, bg)
+    assert_parity(scores, z["bipartite_scores"], TOL, "scores")
+    loss = (scores * t("r_scores")).sum() + float(z["c_emb"]) * (emb * emb.roll(1, 0)).sum()
+    assert abs(float(loss) - float(z["loss"])) <= TOL * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    assert fused.stats["fused_train_calls"] - n0 >= 2 * 6 + 4 * 6   # every cell MLP on the differentiable fused path
+    assert_parity(x.grad, z["grad_x"], TOL, "d loss / d x")
+    assert_parity(emb.grad, z["grad_embeddings"], TOL, "d loss / d embeddings")
+    assert_parity(bw.grad, z["grad_bipartite_edge_weights"], TOL, "d loss / d bipartite_edge_weights")
+    assert_parity(sw.grad, z["grad_super_edge_weights"], TOL, "d loss / d super_edge_weights")
+    params = dict(model.named_parameters())
+    for k in [f[5:] for f in z.files if f.startswith("grad.")]:
+        assert_parity(params[k].grad, z["grad." + k], TOL, k)
+    none = sorted(n for n, p in params.items() if p.grad is None)
+    assert none == sorted(str(n) for n in z["params_without_grad"] if str(n))   # the last cell's unused edge networks
+    _sketch_close(model, z)
 
 
 def test_config4_bc_hgnn_gmm_latent512_bf16_mode():
