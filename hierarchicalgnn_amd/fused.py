@@ -694,14 +694,28 @@ def _split3_head(net, segments, skip) -> bool:
     return all(t.dtype == torch.float32 and int(t.shape[1]) % 128 == 0 for t, _ in segments)
 
 
-def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
+def _out_buffer(out, M, n_out, dtype, dev):
+    """caller-supplied output rows (a contiguous [M, n_out] row block, e.g. a slice of a larger edge table) or a
+    fresh tensor"""
+    if out is None:
+        return torch.empty((M, n_out), dtype=dtype, device=dev)
+    if tuple(out.shape) != (M, n_out) or out.dtype != dtype or out.device != dev or not out.is_contiguous():
+        raise RuntimeError(f"fused_concat_mlp: out must be a contiguous {dtype} [{M}, {n_out}] tensor on {dev}")
+    return out
+
+
+def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor], out: Optional[torch.Tensor] = None):
+    """``out``: write the result rows into this tensor (no-grad callers that assemble one edge table from several
+    calls -- the interior / boundary split of a sharded edge update -- avoid a 2 GB concatenation); only the
+    single-launch paths take it"""
     bf16 = _is_bf16(segments)
     if not bf16 and _split3_head(net, segments, skip):
         mods = list(net)
         body = nn.Sequential(*mods[:6])
         body._hgnn_split3 = True
         hid = fused_concat_mlp(body, segments, None)
-        return torch.nn.functional.linear(hid, mods[6].weight, mods[6].bias)
+        res = torch.nn.functional.linear(hid, mods[6].weight, mods[6].bias)
+        return res if out is None else out.copy_(res)
     if len(_parse(net) or []) > 1:
         if bf16:
             sp = _wants_split(net, segments)
@@ -715,21 +729,21 @@ def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor]):
         if not whole_ok and _chain_supported(net, segments, skip):
             # one launch per layer; the hidden rows make one trip through HBM (fp32 at latent 512)
             chain = _layer_chain(net)
-            segs, out = segments, None
+            segs, out_c = segments, None
             for i, sub in enumerate(chain):
                 if isinstance(sub, nn.Linear):
-                    out = torch.nn.functional.linear(out, sub.weight.to(out.dtype), sub.bias.to(out.dtype))
+                    out_c = torch.nn.functional.linear(out_c, sub.weight.to(out_c.dtype), sub.bias.to(out_c.dtype))
                 else:
-                    out = fused_concat_mlp(sub, segs, skip if i == len(chain) - 1 else None)
-                    segs = [(out, None)]
-            return out
+                    out_c = fused_concat_mlp(sub, segs, skip if i == len(chain) - 1 else None)
+                    segs = [(out_c, None)]
+            return out_c if out is None else out.copy_(out_c)
     split = bf16 and _wants_split(net, segments)
     desc = _descriptor_bf16(net, segments, skip, split) if bf16 else _descriptor(net, segments, skip)
     if desc is None:
         raise RuntimeError("fused_concat_mlp: unsupported arguments (call supported() first)")
     d, keep, M, n_out = desc
     dev = segments[0][0].device
-    out = torch.empty((M, n_out), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+    out = _out_buffer(out, M, n_out, torch.bfloat16 if bf16 else torch.float32, dev)
     if M == 0:
         return out
     lib = _lib.load()

@@ -37,6 +37,8 @@ def _maybe_checkpoint(enabled, fn, *args):
 
 
 class InteractionGNNCell(nn.Module):
+    edge_update_takes_out = True     # edge_update(..., out=rows): partition.py's zero-copy interior / boundary split
+
     def __init__(self, hparams):
         super().__init__()
         L, H = hparams["latent"], hparams["hidden"]
@@ -56,13 +58,18 @@ class InteractionGNNCell(nn.Module):
         return concat_mlp(self.node_network, [(nodes, None), (edge_messages, None)], skip=nodes)
 
     # gnn_utils.py:57-64
-    def _edge_update(self, nodes, edges, graph):
-        return concat_mlp(self.edge_network, [(nodes, graph[0]), (nodes, graph[1]), (edges, None)], skip=edges)
+    def _edge_update(self, nodes, edges, graph, out=None):
+        return concat_mlp(self.edge_network, [(nodes, graph[0]), (nodes, graph[1]), (edges, None)], skip=edges,
+                          out=out)
 
     def node_update(self, nodes, edges, graph):
         return _maybe_checkpoint(self._ckpt, self._node_update, nodes, edges, graph)
 
-    def edge_update(self, nodes, edges, graph):
+    def edge_update(self, nodes, edges, graph, out=None):
+        """``out`` (no-grad): write the updated rows into a caller-supplied row block (partition.py assembles a
+        shard's edge table from an interior and a boundary call)"""
+        if out is not None:
+            return self._edge_update(nodes, edges, graph, out=out)
         return _maybe_checkpoint(self._ckpt, self._edge_update, nodes, edges, graph)
 
     # gnn_utils.py:66-71 -- the edge update sees the UPDATED nodes
@@ -74,6 +81,8 @@ class InteractionGNNCell(nn.Module):
 
 
 class HierarchicalGNNCell(nn.Module):
+    edge_update_takes_out = True
+
     def __init__(self, hparams):
         super().__init__()
         L, H = hparams["latent"], hparams["hidden"]
@@ -102,8 +111,9 @@ class HierarchicalGNNCell(nn.Module):
                           skip=nodes)
 
     # gnn_utils.py:130-135
-    def _edge_update(self, nodes, edges, graph):
-        return concat_mlp(self.edge_network, [(nodes, graph[0]), (nodes, graph[1]), (edges, None)], skip=edges)
+    def _edge_update(self, nodes, edges, graph, out=None):
+        return concat_mlp(self.edge_network, [(nodes, graph[0]), (nodes, graph[1]), (edges, None)], skip=edges,
+                          out=out)
 
     # gnn_utils.py:138-145  (K3 + K4)
     def _supernode_update(self, nodes, supernodes, superedges, bipartite_graph, bipartite_edge_weights,
@@ -127,7 +137,9 @@ class HierarchicalGNNCell(nn.Module):
     def node_update(self, *a):
         return _maybe_checkpoint(self._ckpt, self._node_update, *a)
 
-    def edge_update(self, *a):
+    def edge_update(self, *a, out=None):
+        if out is not None:                      # no-grad, caller-supplied output rows (partition.py)
+            return self._edge_update(*a, out=out)
         return _maybe_checkpoint(self._ckpt, self._edge_update, *a)
 
     def supernode_update(self, *a, node_message_reduce=None):

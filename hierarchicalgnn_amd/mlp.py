@@ -24,11 +24,19 @@ Segment = Tuple[torch.Tensor, Optional[torch.Tensor]]  # (table, index or None)
 
 
 def concat_mlp(net: nn.Sequential, segments: Sequence[Segment], skip: Optional[torch.Tensor] = None,
-               bf16_tail: bool = False) -> torch.Tensor:
+               bf16_tail: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``bf16_tail`` (bf16 latent mode, encoders): when an fp32-input MLP has no fused kernel, keep its
     first Linear in fp32 (hit coordinates must not be rounded to 8 bits) and run the rest -- the wide
     GEMMs -- in bf16; the result is bf16."""
     from . import fused
+    if out is not None:
+        # caller-supplied output rows (no-grad only): straight into the fused kernel when it takes the shape,
+        # otherwise evaluated as usual and copied
+        if torch.is_grad_enabled() and any(t.requires_grad for t, _ in segments):
+            raise RuntimeError("concat_mlp(out=...) is a no-grad path")
+        if not bf16_tail and fused.supported(net, segments, skip):
+            return fused.fused_concat_mlp(net, segments, skip, out=out)
+        return out.copy_(concat_mlp(net, segments, skip, bf16_tail))
     if bf16_tail and skip is None and len(net) > 3 and not torch.is_grad_enabled() and fused._enabled:
         # bf16 latent mode, encoders: hybrid chain -- the first Linear (hit coordinates: must not be rounded to 8
         # bits) as ONE fp32 fused layer, the wide tail on the bf16 feature-split kernel (edge encoder at latent 256,

@@ -43,82 +43,98 @@ class EventShard:
     send_index: torch.Tensor        # [sum(send_splits)] owned local ids, grouped by destination rank
     send_splits: List[int] = field(default_factory=list)
     recv_splits: List[int] = field(default_factory=list)
+    n_interior: int = 0             # local edges [0, n_interior) have an OWNED source (no halo row needed): the
+                                    # edge update of these can run while the halo exchange is in flight
+    partition_s: float = 0.0        # wall seconds partition_event took (host-synchronised)
 
 
-def node_owner(x: torch.Tensor, directed_graph: torch.Tensor, world: int):
-    """phi-ordered contiguous wedges, balanced on in-degree.  Returns (owner[N], pos[N])."""
+def node_owner(x: torch.Tensor, directed_graph: torch.Tensor, world: int, return_order: bool = False):
+    """phi-ordered contiguous wedges, balanced on in-degree.  Returns (owner[N], pos[N]) (+ order[N] = hit at
+    phi position).  Runs on the device of its inputs with no host loop; the balance arithmetic is EXACT integer
+    arithmetic (weight of a hit = 1000 in-degree + 1: hits without edges still cost a row), so every rank -- and
+    the CPU and the GPU -- derive bit-identical cuts."""
     n = x.shape[0]
+    dev = x.device
     order = torch.argsort(x[:, 1], stable=True)
-    pos = torch.empty(n, dtype=torch.long)
-    pos[order] = torch.arange(n)
-    deg = torch.bincount(directed_graph[1], minlength=n).double() + 1e-3  # hits without edges still cost a row
-    cum = torch.cumsum(deg[order], 0)
-    total = float(cum[-1]) if n else 0.0
-    bounds = torch.tensor([total * k / world for k in range(1, world)], dtype=torch.double)
-    cuts = torch.searchsorted(cum, bounds).tolist() if n else []
-    owner_sorted = torch.zeros(n, dtype=torch.long)
-    prev = 0
-    for r, c in enumerate(cuts + [n]):
-        owner_sorted[prev:c] = r
-        prev = max(prev, c)
-    owner = torch.empty(n, dtype=torch.long)
+    pos = torch.empty(n, dtype=torch.long, device=dev)
+    pos[order] = torch.arange(n, device=dev)
+    w = torch.bincount(directed_graph[1], minlength=n) * 1000 + 1
+    cum = torch.cumsum(w[order], 0)
+    if n:
+        total = cum[-1]
+        bounds = (total * torch.arange(1, world, device=dev, dtype=torch.long) + world - 1) // world  # ceil(total k / P)
+        cuts = torch.searchsorted(cum, bounds)
+        owner_sorted = torch.searchsorted(cuts, torch.arange(n, device=dev), right=True)
+    else:
+        owner_sorted = torch.zeros(0, dtype=torch.long, device=dev)
+    owner = torch.empty(n, dtype=torch.long, device=dev)
     owner[order] = owner_sorted
+    if return_order:
+        return owner, pos, order
     return owner, pos
 
 
+def _grouped_unique(group: torch.Tensor, nodes: torch.Tensor, pos: torch.Tensor, order: torch.Tensor, n: int, world: int):
+    """distinct ``nodes`` per ``group`` (a rank id), groups ascending, phi order inside a group:
+    (node ids [sum], counts per group [world]) -- ONE sort-unique of a composite key instead of a loop over peers"""
+    key = torch.unique(group * n + pos[nodes])                      # sorted
+    counts = torch.bincount(torch.div(key, n, rounding_mode="floor"), minlength=world)
+    return order[key % n], counts
+
+
 def partition_event(x: torch.Tensor, edge_index: torch.Tensor, world: int, rank: int,
-                    already_directed: bool = False) -> EventShard:
-    """Shard one event (CPU tensors).  ``edge_index`` is the stored [2,E] graph; it is
-    doubled exactly as the model does (EdgeClassifier/Models/IN.py:122) unless
-    ``already_directed``.  Deterministic: every rank derives the same partition."""
+                    already_directed: bool = False, device=None) -> EventShard:
+    """Shard one event.  ``edge_index`` is the stored [2,E] graph; it is doubled exactly as the model does
+    (EdgeClassifier/Models/IN.py:122) unless ``already_directed``.  Deterministic: every rank derives the same
+    partition.  Runs on ``device`` (default: where the inputs live) with device-wide sort / scan / unique /
+    compaction primitives and no per-peer host loop: on an MI355X the full-pileup event (480k hits, 8M directed
+    edges) partitions in milliseconds instead of the 0.15-0.6 s of the former CPU loops; the gloo CPU tests run the
+    same code on CPU tensors.
+
+    Local edge order: edges whose SOURCE is owned first (``n_interior`` of them), then the cut edges whose source is
+    a halo row; inside each class the order of the global directed graph is kept."""
+    import time
+    t0 = time.perf_counter()
+    if device is not None:
+        x, edge_index = x.to(device), edge_index.to(device)
+    dev = x.device
     graph = edge_index if already_directed else torch.cat([edge_index, edge_index.flip(0)], dim=1)
     n = x.shape[0]
-    owner, pos = node_owner(x, graph, world)
+    owner, pos, order = node_owner(x, graph, world, return_order=True)
     src, dst = graph[0], graph[1]
-    mine = owner[dst] == rank
-    edge_global = torch.nonzero(mine).squeeze(1)
+    so, do = owner[src], owner[dst]
+    mine = do == rank
+    local_src = so == rank
+    e_int = torch.nonzero(mine & local_src).squeeze(1)
+    e_bnd = torch.nonzero(mine & ~local_src).squeeze(1)
+    edge_global = torch.cat([e_int, e_bnd])
+    n_interior = int(e_int.numel())
     e_src, e_dst = src[edge_global], dst[edge_global]
 
-    owned_global = torch.nonzero(owner == rank).squeeze(1)
-    owned_global = owned_global[torch.argsort(pos[owned_global])]          # phi order inside the wedge
-    n_owned = owned_global.numel()
-    g2l = torch.full((n,), -1, dtype=torch.long)
-    g2l[owned_global] = torch.arange(n_owned)
+    owned_global = order[owner[order] == rank]                         # phi order inside the wedge
+    n_owned = int(owned_global.numel())
+    g2l = torch.full((n,), -1, dtype=torch.long, device=dev)
+    g2l[owned_global] = torch.arange(n_owned, device=dev)
 
-    # halo: remote sources of my edges, grouped by owner, phi-ordered inside a group
-    src_owner = owner[e_src]
-    recv_splits, halo_parts = [], []
-    for a in range(world):
-        if a == rank:
-            recv_splits.append(0)
-            continue
-        nodes = torch.unique(e_src[src_owner == a])
-        nodes = nodes[torch.argsort(pos[nodes])]
-        halo_parts.append(nodes)
-        recv_splits.append(int(nodes.numel()))
-    halo_global = torch.cat(halo_parts) if halo_parts else torch.zeros(0, dtype=torch.long)
-    g2l[halo_global] = n_owned + torch.arange(halo_global.numel())
+    # halo: remote sources of my cut edges, grouped by owner, phi-ordered inside a group
+    b_src = src[e_bnd]
+    halo_global, recv_counts = _grouped_unique(owner[b_src], b_src, pos, order, n, world)
+    g2l[halo_global] = n_owned + torch.arange(halo_global.numel(), device=dev)
 
-    # what I must send: my hits that are sources of edges owned by q (same order as q's halo group)
-    dst_owner_all = owner[dst]
-    src_owner_all = owner[src]
-    send_splits, send_parts = [], []
-    for q in range(world):
-        if q == rank:
-            send_splits.append(0)
-            continue
-        nodes = torch.unique(src[(src_owner_all == rank) & (dst_owner_all == q)])
-        nodes = nodes[torch.argsort(pos[nodes])]
-        send_parts.append(g2l[nodes])
-        send_splits.append(int(nodes.numel()))
-    send_index = torch.cat(send_parts) if send_parts else torch.zeros(0, dtype=torch.long)
+    # what I must send: my hits that are sources of edges owned by q (same order as q's halo group for me)
+    out_cut = torch.nonzero(local_src & ~mine).squeeze(1)
+    send_nodes, send_counts = _grouped_unique(do[out_cut], src[out_cut], pos, order, n, world)
+    send_index = g2l[send_nodes]
 
     local_graph = torch.stack([g2l[e_src], g2l[e_dst]]).contiguous()
-    assert int(local_graph.min()) >= 0 if local_graph.numel() else True
+    splits = torch.stack([send_counts, recv_counts]).tolist()         # the ONE host read of the partition
+    if local_graph.numel():
+        assert int(local_graph.min()) >= 0
     return EventShard(rank=rank, world=world, n_global=n, n_owned=n_owned, n_halo=int(halo_global.numel()),
                       owned_global=owned_global, halo_global=halo_global, local_graph=local_graph,
                       edge_global=edge_global, send_index=send_index.contiguous(),
-                      send_splits=send_splits, recv_splits=recv_splits)
+                      send_splits=[int(v) for v in splits[0]], recv_splits=[int(v) for v in splits[1]],
+                      n_interior=n_interior, partition_s=time.perf_counter() - t0)
 
 
 def _pack(rows: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
@@ -198,30 +214,41 @@ class HaloExchange:
         self.recv_splits = list(shard.recv_splits)
         if mode == "all_gather":
             # boundary block = my hits any peer needs (deduplicated), padded to the global max
-            boundary = torch.unique(shard.send_index)
-            t = torch.tensor([boundary.numel()], dtype=torch.long, device=self.device)
+            dev = self.device
+            send_index = shard.send_index.to(dev)
+            owned_global = shard.owned_global.to(dev)
+            halo_global = shard.halo_global.to(dev)
+            boundary = torch.unique(send_index)
+            t = torch.tensor([boundary.numel()], dtype=torch.long, device=dev)
             sizes = [torch.zeros_like(t) for _ in range(shard.world)]
             dist.all_gather(sizes, t, group=group)
-            self.block = max(1, max(int(s_.item()) for s_ in sizes))
-            pad = torch.zeros(self.block - boundary.numel(), dtype=torch.long)
-            self.boundary_index = torch.cat([boundary, pad]).to(self.device)
+            self.block = max(1, int(torch.stack(sizes).max().item()))
+            pad = torch.zeros(self.block - boundary.numel(), dtype=torch.long, device=dev)
+            self.boundary_index = torch.cat([boundary, pad])
             # where, in the gathered [world*block] buffer, does each of my halo rows sit?
             # every rank needs the boundary lists of its peers: exchange them once.
-            mine = torch.full((self.block,), -1, dtype=torch.long)
-            mine[:boundary.numel()] = shard.owned_global[boundary]
-            lists = [torch.empty(self.block, dtype=torch.long, device=self.device) for _ in range(shard.world)]
-            dist.all_gather(lists, mine.to(self.device), group=group)
-            flat = torch.cat([l.cpu() for l in lists])
+            mine = torch.full((self.block,), -1, dtype=torch.long, device=dev)
+            mine[:boundary.numel()] = owned_global[boundary]
+            lists = [torch.empty(self.block, dtype=torch.long, device=dev) for _ in range(shard.world)]
+            dist.all_gather(lists, mine, group=group)
+            flat = torch.cat(lists)
             # position of every halo hit inside the gathered buffer (vectorised lookup)
             valid = torch.nonzero(flat >= 0).squeeze(1)
             keys, order = torch.sort(flat[valid])
-            pos = torch.searchsorted(keys, shard.halo_global)
-            assert bool((keys[pos.clamp(max=max(keys.numel() - 1, 0))] == shard.halo_global).all()) \
-                if shard.halo_global.numel() else True
-            self.halo_from_gathered = valid[order[pos]].to(self.device) if shard.halo_global.numel() \
-                else torch.zeros(0, dtype=torch.long, device=self.device)
+            if halo_global.numel():
+                pos = torch.searchsorted(keys, halo_global)
+                assert bool((keys[pos.clamp(max=max(keys.numel() - 1, 0))] == halo_global).all())
+                self.halo_from_gathered = valid[order[pos]]
+            else:
+                self.halo_from_gathered = torch.zeros(0, dtype=torch.long, device=dev)
         elif mode != "all_to_all":
             raise ValueError(mode)
+
+    def side_stream(self):
+        """the HIP stream the overlapped exchange runs on (one per HaloExchange, created on first use)"""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
 
     def exchange(self, nodes_owned: torch.Tensor) -> torch.Tensor:
         """rows of the remote sources of my edges, [n_halo, L]"""
@@ -239,10 +266,70 @@ class HaloExchange:
         return 4 * latent * self.shard.n_halo
 
 
-def distributed_cell_forward(cell, halo: HaloExchange, nodes_owned, edges_local, local_graph):
+def _graph_cols(graph, a, b):
+    """columns [a, b) of a [2, M] graph as a contiguous [2, b - a] tensor whose rows are VIEWS-stable per call site:
+    plans / int32 copies are cached on the identity of the index tensors, so the slices are made once per shard"""
+    return graph[:, a:b].contiguous()
+
+
+def _split_edge_update(cell, halo: "HaloExchange", nodes_owned, edges_local, local_graph, n_interior):
+    """The edge update of a shard (Modules/gnn_utils.py:57-64) with the halo exchange HIDDEN behind the interior
+    edges: edges [0, n_interior) have an owned source, so their MLP needs no remote row and runs on
+    the current stream while the exchange (pack kernel -> RCCL -> unpack) runs on a side stream; the cut edges
+    [n_interior, M) -- a fraction of a percent with phi-wedges -- follow once the halo has landed.  Without autograd
+    both calls write straight into one output table (no concatenation); under autograd the two results are
+    concatenated (the backward of the exchange returns halo gradients to their owners as before)."""
+    M = int(edges_local.shape[0])
+    ni = int(n_interior)
+    cache = halo.__dict__.setdefault("_split_graphs", {})
+    key = (local_graph.data_ptr(), M, ni)
+    if key not in cache:
+        cache.clear()
+        cache[key] = (_graph_cols(local_graph, 0, ni), _graph_cols(local_graph, ni, M), local_graph)
+    g_int, g_bnd, _ = cache[key]
+    e_int, e_bnd = edges_local[:ni], edges_local[ni:]
+    # zero-copy assembly needs a cell whose edge_update writes into caller-supplied rows (the HIP cells do)
+    no_grad = not (torch.is_grad_enabled() and (nodes_owned.requires_grad or edges_local.requires_grad)) \
+        and getattr(cell, "edge_update_takes_out", False)
+    out = torch.empty_like(edges_local) if no_grad else None
+
+    def interior():
+        if ni == 0:
+            return e_int
+        return cell.edge_update(nodes_owned, e_int, g_int, out=out[:ni]) if no_grad \
+            else cell.edge_update(nodes_owned, e_int, g_int)
+
+    if nodes_owned.is_cuda:
+        cur = torch.cuda.current_stream(nodes_owned.device)
+        side = halo.side_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            halo_rows = halo.exchange(nodes_owned)
+        nodes_owned.record_stream(side)
+        new_int = interior()
+        cur.wait_stream(side)
+        halo_rows.record_stream(cur)
+    else:                                            # gloo / CPU rehearsal: same schedule, sequentially
+        halo_rows = halo.exchange(nodes_owned)
+        new_int = interior()
+    if M == ni:
+        return new_int if not no_grad else out
+    nodes_ext = torch.cat([nodes_owned, halo_rows], dim=0)
+    if no_grad:
+        cell.edge_update(nodes_ext, e_bnd, g_bnd, out=out[ni:])
+        return out
+    new_bnd = cell.edge_update(nodes_ext, e_bnd, g_bnd)
+    return torch.cat([new_int, new_bnd], dim=0)
+
+
+def distributed_cell_forward(cell, halo: HaloExchange, nodes_owned, edges_local, local_graph, overlap: bool = True):
     """InteractionGNNCell.forward (Modules/gnn_utils.py:66-71) on one shard:
-    local aggregation + node MLP, ONE halo exchange, then the edge update."""
+    local aggregation + node MLP, ONE halo exchange, then the edge update.  ``overlap``: run the exchange on a side
+    stream under the interior edges' MLP (needs the shard's interior-first edge order, ``shard.n_interior``)."""
     nodes_owned = cell.node_update(nodes_owned, edges_local, local_graph)
+    if overlap and halo.shard.n_interior > 0 and int(edges_local.shape[0]) == int(halo.shard.local_graph.shape[1]):
+        edges_local = _split_edge_update(cell, halo, nodes_owned, edges_local, local_graph, halo.shard.n_interior)
+        return nodes_owned, edges_local
     nodes_ext = halo.extend(nodes_owned)
     edges_local = cell.edge_update(nodes_ext, edges_local, local_graph)
     return nodes_owned, edges_local
@@ -320,7 +407,8 @@ def shard_bipartite(shard: EventShard, bipartite_graph: torch.Tensor, bipartite_
 
 
 def distributed_hgnn_cell_forward(cell, halo: HaloExchange, nodes_owned, edges_local, supernodes, superedges,
-                                  local_graph, bipartite_local, bipartite_w_local, super_graph, super_w, group=None):
+                                  local_graph, bipartite_local, bipartite_w_local, super_graph, super_w, group=None,
+                                  overlap: bool = True):
     """HierarchicalGNNCell.forward (Modules/gnn_utils.py:155-169) on one shard.  Supernodes and
     superedges are replicated (every rank computes their small updates redundantly); the only
     collectives are the all_reduce of the node->supernode sums and the halo exchange before the
@@ -333,6 +421,11 @@ def distributed_hgnn_cell_forward(cell, halo: HaloExchange, nodes_owned, edges_l
                                        node_message_reduce=lambda t: allreduce_supernode_sums(t, group))
     nodes_owned = cell.node_update(nodes_owned, edges_local, supernodes, local_graph, bipartite_local,
                                    bipartite_w_local)
+    if overlap and halo.shard.n_interior > 0 and int(edges_local.shape[0]) == int(halo.shard.local_graph.shape[1]):
+        # the exchange also hides behind the (replicated, small) superedge update
+        superedges = cell.superedge_update(supernodes, superedges, super_graph, super_w)
+        edges_local = _split_edge_update(cell, halo, nodes_owned, edges_local, local_graph, halo.shard.n_interior)
+        return nodes_owned, edges_local, supernodes, superedges
     superedges = cell.superedge_update(supernodes, superedges, super_graph, super_w)
     nodes_ext = halo.extend(nodes_owned)
     edges_local = cell.edge_update(nodes_ext, edges_local, local_graph)

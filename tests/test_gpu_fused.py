@@ -375,9 +375,9 @@ def test_bc_forward_latent256_has_no_library_mlp():
     calls = {"n": 0}
     real = mlp.concat_mlp
 
-    def counting(net, segments, skip=None, bf16_tail=False):
+    def counting(net, segments, skip=None, bf16_tail=False, out=None):
         calls["n"] += 1
-        return real(net, segments, skip, bf16_tail)
+        return real(net, segments, skip, bf16_tail, out)
 
     import hierarchicalgnn_amd.gnn_utils as gu
     import hierarchicalgnn_amd.models as mo

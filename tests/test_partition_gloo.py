@@ -133,8 +133,9 @@ def test_partitioned_cell_matches_single_process(world, mode):
     for rank, owned, eglob, out_n, out_e, gn, ge, pooled, n_halo, ss, rs in results:
         seen_nodes[owned] += 1
         seen_edges[eglob] += 1
-        assert torch.allclose(out_n, on.detach()[owned], rtol=1e-5, atol=1e-6)
-        assert torch.allclose(out_e, oe.detach()[eglob], rtol=1e-5, atol=1e-6)
+        # (the shard lists its interior edges first: a destination's fp32 arrival-order sum is re-associated)
+        assert torch.allclose(out_n, on.detach()[owned], rtol=1e-5, atol=5e-6)
+        assert torch.allclose(out_e, oe.detach()[eglob], rtol=1e-5, atol=5e-6)
         assert torch.allclose(ge, e_ref.grad[eglob], rtol=1e-4, atol=1e-5)
         assert torch.allclose(gn, n_ref.grad[owned], rtol=1e-4, atol=1e-5)
         assert torch.allclose(pooled, pooled_ref, rtol=1e-5, atol=1e-5)
@@ -222,9 +223,10 @@ def _real_cell_on_cpu(sd):
             rows = rows * weight
         return O.scatter_add(rows, dst_index, 0, dim_size)
 
-    def concat_mlp(net, segments, skip=None, bf16_tail=False):
+    def concat_mlp(net, segments, skip=None, bf16_tail=False, out=None):
         y = net(torch.cat([t if i is None else t[i] for t, i in segments], dim=-1))
-        return y if skip is None else y + skip
+        y = y if skip is None else y + skip
+        return y if out is None else out.copy_(y)
 
     gnn_utils.scatter_add, gnn_utils.gather_scale_scatter, gnn_utils.concat_mlp = \
         scatter_add, gather_scale_scatter, concat_mlp
@@ -303,7 +305,7 @@ def test_partitioned_hierarchical_cell_matches_single_process(real_cell):
                 ref_g = ref_params[nm].grad
                 assert torch.allclose(g, ref_g, rtol=2e-4, atol=2e-5 * max(1.0, float(ref_g.abs().max()))), nm
     # the real cell evaluates nn.Sequential modules, the oracle its own restatement: fp32 rounding differs
-    tol = dict(rtol=1e-4, atol=1e-5) if real_cell else dict(rtol=1e-5, atol=1e-6)
+    tol = dict(rtol=1e-4, atol=1e-5) if real_cell else dict(rtol=1e-5, atol=5e-6)   # interior-first edge order re-associates the sums
     for rank, owned, eglob, a, b, c, d, gn, ge, gsn, gse, *_ in results:
         assert torch.allclose(a, on.detach()[owned], **tol)
         assert torch.allclose(b, oe.detach()[eglob], **tol)
