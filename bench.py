@@ -169,7 +169,7 @@ class Workload:
             self.n_local = self.n_hits
         else:
             from hierarchicalgnn_amd import partition
-            self.shard = partition.partition_event(x, ei, world, rank)
+            self.shard = partition.partition_event(x, ei, world, rank, device=device)   # on the GPU: device-wide sort / unique / compaction
             graph = self.shard.local_graph
             self.dst_cpu = None
             self.n_local = self.shard.n_owned
@@ -374,6 +374,7 @@ def measure(args, scaling: str, world: int, rank: int, device, dist, coll_device
         "halo_mode": wl.halo_mode,
         "k1_launch_ms": kern_ms,
         "setup_s": {"synth": wl.synth_s, "partition_and_halo_tables": wl.partition_s,
+                    "partition_event_only": wl.shard.partition_s if wl.shard is not None else 0.0,
                     "total_before_first_step": setup_s},
         "plan_build_ms": plan_ms,
         "plan_chunk": plan.chunk,

@@ -31,6 +31,32 @@ def symmetrize(src: torch.Tensor, dst: torch.Tensor, n: int):
     return torch.div(key, n, rounding_mode="floor"), key % n
 
 
+def batch_norm_1(bn: nn.BatchNorm1d, x: torch.Tensor, stat_reduce=None) -> torch.Tensor:
+    """``bn(x.unsqueeze(1)).squeeze()`` for the one-channel BatchNorm of gnn_utils.py:179,209.  With ``stat_reduce``
+    (a differentiable sum over the shards of ONE event, partition.allreduce_supernode_sums) and the module in
+    training mode the batch statistics are those of the WHOLE event: every rank contributes (sum, sum of squares,
+    count) of its own edges -- a synchronised BatchNorm; running statistics are updated exactly as nn.BatchNorm1d
+    does (momentum, unbiased variance).  Gradients flow through the reduced statistics: the backward of the sum over
+    ranks is again a sum over ranks, which is what makes d loss / d x_i see the other shards' loss terms."""
+    if stat_reduce is None or not bn.training:
+        return bn(x.unsqueeze(1)).squeeze(1)
+    xd = x.double()
+    stats = stat_reduce(torch.stack([xd.sum(), (xd * xd).sum(), xd.new_tensor(float(x.numel()))]))
+    n = stats[2]
+    mean = stats[0] / n
+    var = (stats[1] / n - mean * mean).clamp(min=0)                 # biased, as the normalisation uses
+    with torch.no_grad():
+        if bn.track_running_stats and bn.running_mean is not None:
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - m).add_(m * mean.to(bn.running_mean.dtype))
+            bn.running_var.mul_(1 - m).add_(m * (var * n / (n - 1).clamp(min=1)).to(bn.running_var.dtype))
+    y = ((xd - mean) * torch.rsqrt(var + bn.eps)).to(x.dtype)
+    if bn.affine:
+        y = y * bn.weight[0] + bn.bias[0]
+    return y
+
+
 class DynamicGraphConstruction(nn.Module):
     def __init__(self, weighting_function, hparams):
         super().__init__()
@@ -57,10 +83,11 @@ class DynamicGraphConstruction(nn.Module):
                 self.knn_radius = 0.9 * self.knn_radius + 0.11 * maximum_dist
         return graph
 
-    def edge_weights(self, src_embeddings, dst_embeddings, graph, norm=False, logits=False):
-        """gnn_utils.py:208-216: dot product -> BatchNorm1d(1) -> weighting function (-> /mean)"""
+    def edge_weights(self, src_embeddings, dst_embeddings, graph, norm=False, logits=False, stat_reduce=None):
+        """gnn_utils.py:208-216: dot product -> BatchNorm1d(1) -> weighting function (-> /mean).
+        ``stat_reduce``: the edges are one shard of an event (partition.py): synchronised batch statistics"""
         likelihood = edge_dot(src_embeddings, graph[0], dst_embeddings, graph[1])
-        edge_weights_logits = self.weight_normalization(likelihood.unsqueeze(1)).squeeze()
+        edge_weights_logits = batch_norm_1(self.weight_normalization, likelihood, stat_reduce)
         edge_weights = self.weighting_function(edge_weights_logits)
         if norm:
             edge_weights = edge_weights / edge_weights.mean()

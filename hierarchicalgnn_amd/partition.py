@@ -576,8 +576,8 @@ def distributed_bc_forward(pieces, shard: EventShard, halo: HaloExchange, x_owne
     one MI355X -- is run REDUNDANTLY by every rank on identical inputs (deterministic kernels => identical
     clusters everywhere, no label-exchange protocol); centroids, the super graph, supernodes and superedges are
     replicated; the node->supernode sums (K5, K3) are all-reduced; the bipartite weights' mean-normalisation
-    (gnn_utils.py:213) uses the all-reduced global mean.  BatchNorm statistics must be frozen (eval mode): the
-    training-mode batch statistics of gnn_utils.py:209 would need a synchronised BatchNorm.
+    (gnn_utils.py:213) uses the all-reduced global mean; in training mode the BatchNorm in front of those weights
+    (gnn_utils.py:209) uses batch statistics synchronised over the ranks (``bc_pieces_from_model``).
     Returns (bipartite graph [global hit id, supernode id], scores, embeddings of the owned hits)."""
     dev = x_owned.device
     graph = shard.local_graph.to(dev)
@@ -608,16 +608,17 @@ def distributed_bc_forward(pieces, shard: EventShard, halo: HaloExchange, x_owne
     return bg_global, scores, emb_owned
 
 
-def bc_pieces_from_model(model):
-    """``pieces`` of a ``hierarchicalgnn_amd.models.BC_MessagePassing`` for ``distributed_bc_forward`` (GPU)"""
+def bc_pieces_from_model(model, group=None):
+    """``pieces`` of a ``hierarchicalgnn_amd.models.BC_MessagePassing`` for ``distributed_bc_forward`` (GPU).
+    Training mode: the bipartite attention weights' BatchNorm1d(1) (gnn_utils.py:179,209) sees only this rank's
+    bipartite edges, so its batch statistics are SYNCHRONISED over ``group`` (graph_construction.batch_norm_1); the
+    super graph is replicated (identical inputs on every rank), its BatchNorm needs no collective."""
     from .mlp import concat_mlp
     from .ops import gather_scale_scatter, l1_row_scale, scatter_add
     import torch.nn as nn
     blk, hb = model.ignn_block, model.hgnn_block
-    if hb.super_graph_construction.training or hb.bipartite_graph_construction.training:
-        raise RuntimeError("distributed_bc_forward needs frozen BatchNorm statistics (model.eval()); the training-mode "
-                           "batch statistics of gnn_utils.py:209 would need a synchronised BatchNorm")
     hp = model.hparams
+    sync_stats = lambda t: allreduce_supernode_sums(t, group)
 
     def centroids(emb, clusters, n):
         lab = torch.where(clusters >= 0, clusters, torch.full_like(clusters, n)).contiguous()
@@ -629,7 +630,7 @@ def bc_pieces_from_model(model):
     def bipartite(emb_owned, means):
         gc = hb.bipartite_graph_construction
         g = gc.build_graph(emb_owned, means, sym=False, k=hp["bipartitegraph_sparsity"])
-        return g, gc.edge_weights(emb_owned, means, g, norm=False)
+        return g, gc.edge_weights(emb_owned, means, g, norm=False, stat_reduce=sync_stats if gc.training else None)
 
     return dict(
         node_encode=blk._encode_nodes, edge_encode=blk._encode_edges, ignn_cells=list(blk.ignn_cells),

@@ -628,3 +628,66 @@ def test_partitioned_bc_model_matches_single_process():
             assert abs(ref_map[(a, b)] - v) <= 2e-5
             seen += 1
     assert seen == len(ref_map)                                           # every bipartite edge exactly once
+
+
+# ---------------------------------------------------------------- synchronised BatchNorm1d(1) of the sharded bipartite weights
+def _syncbn_worker(rank, world, port, q):
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
+    try:
+        from hierarchicalgnn_amd.graph_construction import batch_norm_1
+        torch.set_num_threads(1)
+        g = torch.Generator().manual_seed(4)
+        x_all = torch.randn(1001, generator=g) * 0.7 + 0.3
+        r_all = torch.randn(1001, generator=g)
+        cut = [0, 377, 1001] if world == 2 else [0, 200, 650, 1001]
+        x = x_all[cut[rank]:cut[rank + 1]].clone().requires_grad_(True)
+        bn = torch.nn.BatchNorm1d(1)
+        with torch.no_grad():
+            bn.weight.fill_(1.3)
+            bn.bias.fill_(-0.2)
+        bn.train()
+        y = batch_norm_1(bn, x, lambda t: partition.allreduce_supernode_sums(t))
+        w = torch.exp(y)
+        (w * r_all[cut[rank]:cut[rank + 1]]).sum().backward()
+        partition.allreduce_gradients(bn.parameters())
+        q.put(_by_value((rank, y.detach(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                         bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_synchronised_batch_norm_matches_the_whole_event(world):
+    """training-mode BatchNorm1d(1) over a SHARDED vector of bipartite-edge likelihoods (gnn_utils.py:179,209):
+    outputs, input gradients, affine gradients (after allreduce_gradients) and running statistics equal
+    nn.BatchNorm1d on the whole vector"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((_from_value(q.get(timeout=120)) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(4)
+    x_all = (torch.randn(1001, generator=g) * 0.7 + 0.3).requires_grad_(True)
+    r_all = torch.randn(1001, generator=g)
+    bn = torch.nn.BatchNorm1d(1)
+    with torch.no_grad():
+        bn.weight.fill_(1.3)
+        bn.bias.fill_(-0.2)
+    bn.train()
+    y = bn(x_all.unsqueeze(1)).squeeze(1)
+    (torch.exp(y) * r_all).sum().backward()
+    ys = torch.cat([r[1] for r in results])
+    gx = torch.cat([r[2] for r in results])
+    assert torch.allclose(ys, y.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(gx, x_all.grad, rtol=1e-4, atol=1e-5)
+    for r in results:
+        assert torch.allclose(r[3], bn.weight.grad, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(r[4], bn.bias.grad, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(r[5], bn.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(r[6], bn.running_var, rtol=1e-5, atol=1e-6)
+        assert r[7] == 1
