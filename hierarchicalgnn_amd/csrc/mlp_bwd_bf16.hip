@@ -23,7 +23,6 @@
 
 namespace hgnn {
 extern int g_opt_mlp_ablate;
-int g_opt_bwd_shape = 0;   // hgnn_set_option("mlp_bwd_shape"): N = 512: 0 = 8 waves (default); 1 = 4 waves, z' reloaded (A/B, slower)
 namespace bw {
 using namespace fs;
 
@@ -372,11 +371,9 @@ static int dispatch(const Args& a, int N, hipStream_t s) {
         // N = 512: 8 waves share the 64 rows (an eighth of the features each, one workgroup per CU): with 4 waves the
         // LayerNorm form needs the 128 accumulators AND the 64 registers of raw z' per lane and spills 171 registers
         case 512:
-            // default: 8 waves share the 64 rows (an eighth of the features each, z' kept in registers, one
-            // workgroup per CU).  A/B (hgnn_set_option "mlp_bwd_shape" = 1): 4 waves, 2 workgroups per CU, z'
-            // reloaded per phase -- the LayerNorm form still spills 125 registers there and measured 6.2 vs 3.2 ms
-            // (K = 256, M = 2M; the unfused library GEMM + two row passes: 4.4 ms)
-            if (g_opt_bwd_shape == 1) return launch<8, EPI, 2, 2, 4, false>(a, s);
+            // 8 waves share the 64 rows (an eighth of the features each, z' kept in registers, one workgroup per CU).
+            // (round-2 null result, removed: 4 waves, 2 workgroups per CU, z' reloaded per phase -- the LayerNorm form
+            // still spills 125 registers and measured 6.2 vs 3.2 ms at K = 256, M = 2M)
             return launch<4, EPI, 0, 1, 8>(a, s);
     }
     set_error("hgnn_mlp_backward_layer_bf16: N = %d has no instantiation (128, 256, 512)", N);

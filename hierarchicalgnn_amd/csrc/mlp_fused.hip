@@ -34,7 +34,6 @@
 
 namespace hgnn {
 
-int g_opt_mlp_f32_waves = 4;  // hgnn_set_option("mlp_f32_waves"): 4 (default) or 8 waves per workgroup (L=256 edge kernel)
 int g_opt_mlp_ablate = 0;   // set through hgnn_set_option("mlp_ablate", bits): DIAGNOSTIC, wrong results
 
 struct MlpArgs {
@@ -414,12 +413,8 @@ static int launch_mlp(const MlpArgs& a, hipStream_t s) {
     bool hidden_gelu = true;
     for (int l = 0; l + 1 < n; ++l) hidden_gelu = hidden_gelu && a.act[l] == HGNN_ACT_GELU;
     const int out = a.act[n - 1];
-    // A/B (hgnn_set_option "mlp_f32_waves" = 8): 8 waves = 128 rows per workgroup, one workgroup per CU --
-    // the same two waves per SIMD, half the weight staging per row
-    if constexpr (NT1 == 32 && NT3 == 0) {
-        if (g_opt_mlp_f32_waves == 8 && hidden_gelu && out == HGNN_ACT_TANH)
-            return launch_mlp_act<NT1, NT2, NT3, 1, HGNN_ACT_GELU, HGNN_ACT_TANH, false, 8>(a, s);
-    }
+    // (round-2 null result, removed: 8 waves = 128 rows per workgroup, one workgroup per CU -- bitwise equal,
+    // 3.6 % slower: one phase-locked workgroup does not overlap its epilogue with another's MFMAs)
     if (hidden_gelu && out == HGNN_ACT_TANH) return launch_mlp_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_TANH>(a, s);
     if (hidden_gelu && out == HGNN_ACT_GELU) return launch_mlp_act<NT1, NT2, NT3, MINW, HGNN_ACT_GELU, HGNN_ACT_GELU>(a, s);
     return launch_mlp_act<NT1, NT2, NT3, MINW, -1, -1>(a, s);

@@ -388,7 +388,6 @@ static int launch_b_act(const MlpArgsBf16& a, hipStream_t s) {
     return HGNN_OK;
 }
 
-int g_opt_mlp_bf16_shape = 1;  // hgnn_set_option("mlp_bf16_shape"): 0 = 16 edges/wave, 2-deep ring; 1 = 32 edges/wave, 3-deep ring
 
 template <int NT1, int NT2, int NT3, int MINW, int EG, int NBUF>
 static int launch_b_shape(const MlpArgsBf16& a, hipStream_t s) {
@@ -406,7 +405,7 @@ static int launch_b(const MlpArgsBf16& a, hipStream_t s) {
     // wide layers: 32 edges per wave (one weight fragment feeds two MFMAs), one workgroup per CU,
     // 3-deep weight ring; narrow layers keep 16 edges per wave at higher occupancy
     if constexpr (NT1 >= 16) {
-        if (g_opt_mlp_bf16_shape == 1) return launch_b_shape<NT1, NT2, NT3, 1, 2, 3>(a, s);
+        return launch_b_shape<NT1, NT2, NT3, 1, 2, 3>(a, s);
     }
     return launch_b_shape<NT1, NT2, NT3, MINW, 1, 2>(a, s);
 }

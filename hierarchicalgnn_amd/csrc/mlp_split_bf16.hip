@@ -22,7 +22,6 @@
 
 namespace hgnn {
 extern int g_opt_mlp_ablate;
-int g_opt_mlp_split_shape = -1;    // hgnn_set_option("mlp_split_shape"): -1 auto, 0 = 4 waves x 64 rows, 1 = 8 waves (L=256: x 128 rows, L=512: x 64 rows)
 int g_opt_mlp_split_variant = -1;  // hgnn_set_option("mlp_split_variant"): -1 auto, 0 counted waits, 2 burst
 namespace fs {
 
@@ -568,23 +567,21 @@ extern "C" int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hg
         switch (o) {
             case 128: return fs::launch<4, 2, 0, 2>(a, stream);
             case 256:
-                if (g_opt_mlp_split_shape == 1) return fs::launch<4, 2, 0, 1, 8, 8>(a, stream);  // A/B only: slower
-                // (measured in round 2 and removed again: 4 waves x 128 rows -- one weight fragment feeds 8 MFMAs, half
+                // (round-2 null results, removed: 8 waves x 128 rows in this kernel, 3.11 vs 2.7 ms;
+                // 4 waves x 128 rows -- one weight fragment feeds 8 MFMAs, half
                 // the L1 weight traffic per FLOP, 256 accumulators per lane, one wave per SIMD -- spills 219 registers
                 // under hipcc and runs at 4.35 ms vs 2.9 ms)
                 return fs::launch<8, 4, 0, 2>(a, stream);
             case 512:
                 // 8 waves share the 64 rows (2 per SIMD instead of 1): 8.6 vs 9.6 ms at M = 2M
-                if (g_opt_mlp_split_shape != 0) return fs::launch<8, 4, 0, 1, 8, 4>(a, stream);
-                return fs::launch<16, 8, 0, 1>(a, stream);
+                return fs::launch<8, 4, 0, 1, 8, 4>(a, stream);
         }
     } else {
         switch (o) {
             case 128: return fs::launch<4, 4, 2, 2>(a, stream);
             case 256: return fs::launch<8, 8, 4, 2>(a, stream);
             case 512:
-                if (g_opt_mlp_split_shape != 0) return fs::launch<8, 8, 4, 1, 8, 4>(a, stream);
-                return fs::launch<16, 16, 8, 1>(a, stream);
+                return fs::launch<8, 8, 4, 1, 8, 4>(a, stream);
         }
     }
     set_error("hgnn_mlp_forward_bf16_split: no instantiation");

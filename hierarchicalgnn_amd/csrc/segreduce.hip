@@ -25,11 +25,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern int g_opt_mlp_ablate;
 extern int g_opt_mlp_split_variant;
-extern int g_opt_mlp_f32_waves;
-extern int g_opt_mlp_split_shape;
-extern int g_opt_mlp_bf16_shape;
-extern int g_opt_bwd_shape;
-extern int g_opt_mlp_rows128;
 
 static int g_opt_nt_loads = 1;   // non-temporal loads for once-read source rows
 static int g_opt_nt_stores = 0;  // non-temporal stores for gather output
@@ -140,76 +135,6 @@ __global__ __launch_bounds__(WPB * 64) void k_seg_reduce(
             const int cv = c + v * 64;
             if (cv < nvec) *(f32x4*)(op + cv * 4) = acc[v];
         }
-    }
-}
-
-// Narrow rows (F <= 128 floats: RL <= 32 lanes cover a row, G = 64/RL >= 2 row slots per wave instruction).
-// With one wave per destination a wave moves only deg * F * 4 bytes (2 KB at F = 32, deg = 17) per chain of
-// dependent memory latencies (work-item triple -> row ids -> rows), and the chip runs out of waves before
-// it runs out of bandwidth (52-55 % of peak at F = 32 / 64).  Here every RL-lane GROUP of a wave owns its
-// own work item: G destinations per wave, each group walking its list U rows at a time.  Per wave
-// instruction the access pattern is the same (G whole rows), but a wave now carries G lists' worth of
-// bytes per latency chain, there are G times fewer waves to launch, and the cross-group shuffle reduction
-// disappears (a destination's rows are summed in list order by one lane group: still a fixed order).
-template <int RL, int U, bool HAS_W, bool HAS_RS, bool NT, int TAG, int WPB>
-__global__ __launch_bounds__(WPB * 64) void k_seg_reduce_grouped(
-    const float* __restrict__ src, int F, int nvec, const int32_t* __restrict__ src_row,
-    const int32_t* __restrict__ perm, const float* __restrict__ weight,
-    const float* __restrict__ row_scale, const int32_t* __restrict__ wi_begin,
-    const int32_t* __restrict__ wi_end, const int32_t* __restrict__ wi_target,
-    const int32_t* __restrict__ n_items_ptr, int64_t max_items, float* __restrict__ out,
-    float* __restrict__ partial) {
-    constexpr int G = 64 / RL;
-    const int lane = threadIdx.x & 63;
-    const int g = lane / RL;
-    const int c = lane % RL;
-    const int64_t item = ((int64_t)blockIdx.x * WPB + (threadIdx.x >> 6)) * G + g;
-    const int n_items = *n_items_ptr;
-    const bool live = item < n_items && item < max_items;
-    int begin = 0, end = 0, target = 0;
-    if (live) {
-        begin = wi_begin[item];
-        end = wi_end[item];
-        target = wi_target[item];
-    }
-    const bool col_ok = c < nvec;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int base = begin; base < end; base += RL) {   // trip count differs between groups: lanes of a
-        const int n = (end - base) < RL ? (end - base) : RL;  // finished group simply idle (exec mask)
-        int my_row = 0;
-        float my_w = 1.f;
-        if (c < n) {
-            const int p = base + c;
-            my_row = src_row != nullptr ? src_row[p] : p;
-            if (HAS_W) my_w = weight[perm != nullptr ? perm[p] : p];
-            if (HAS_RS) my_w *= row_scale[my_row];
-        }
-        for (int j = 0; j < n; j += U) {
-            f32x4 val[U];
-            float w[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = j + u;
-                const int from = g * RL + (e & (RL - 1));  // a lane of MY group: same loop iteration, active
-                const int r = __shfl(my_row, from);
-                w[u] = (HAS_W || HAS_RS) ? __shfl(my_w, from) : 1.f;
-                if (e < n && col_ok)
-                    val[u] = ld4(src + (size_t)r * (size_t)F + c * 4, NT);
-                else
-                    val[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (HAS_W || HAS_RS)
-                    acc += val[u] * w[u];
-                else
-                    acc += val[u];
-            }
-        }
-    }
-    if (live && col_ok) {
-        float* op = target >= 0 ? out + (size_t)target * (size_t)F : partial + (size_t)(~target) * (size_t)F;
-        *(f32x4*)(op + c * 4) = acc;
     }
 }
 
@@ -479,9 +404,9 @@ struct SegArgs {
     float *out, *partial;
 };
 
-static int g_opt_seg_unroll = 16;  // rows in flight per wave for 1-KiB rows (F in (128,256])
-static int g_opt_seg_wpb = 16;     // waves per workgroup
-static int g_opt_seg_xcd = 0;      // XCD-contiguous work-item mapping
+// 1-KiB rows (F in (128, 256], the headline shape): 16 rows in flight per wave, 16 waves per workgroup, plain
+// work-item order.  Round-1 sweep of 40 variants (U in {2,4,8,16} x waves in {4,8,16} x XCD-contiguous remap x
+// non-temporal loads, profiles/r01_tune_k1_L256.txt): 421-457 us, this one fastest; the XCD remap is 3-4 % slower.
 
 template <int RL, int VPL, int U, bool W, bool RS, bool NT, int TAG, int WPB, bool XCD>
 static void launch_seg3(const SegArgs& a, hipStream_t s) {
@@ -494,26 +419,6 @@ static void launch_seg3(const SegArgs& a, hipStream_t s) {
         a.wi_target, a.n_items, a.max_items, a.out, a.partial);
 }
 
-static int g_opt_seg_grouped = 0;  // narrow rows: 1 = one work item per RL-lane group; 0 (default) = one per wave.
-                                   // Measured A/B (profiles/r02_k1_widths.json): grouped is 2-5 % SLOWER at F = 32/64/128 --
-                                   // the narrow-row plateau (~50 % of peak at 128-B rows) is not a wave-count / latency limit
-
-template <int RL, int U, bool W, bool RS, int TAG>
-static void launch_seg_grouped(const SegArgs& a, hipStream_t s) {
-    constexpr int WPB = 4, G = 64 / RL;
-    const unsigned grid = (unsigned)ceil_div(a.max_items, WPB * G);
-    if (grid == 0) return;
-    const int nvec = a.F / 4;
-    if (g_opt_nt_loads)
-        k_seg_reduce_grouped<RL, U, W, RS, true, TAG, WPB><<<grid, WPB * 64, 0, s>>>(
-            a.src, a.F, nvec, a.src_row, a.perm, a.weight, a.row_scale, a.wi_begin, a.wi_end, a.wi_target,
-            a.n_items, a.max_items, a.out, a.partial);
-    else
-        k_seg_reduce_grouped<RL, U, W, RS, false, TAG, WPB><<<grid, WPB * 64, 0, s>>>(
-            a.src, a.F, nvec, a.src_row, a.perm, a.weight, a.row_scale, a.wi_begin, a.wi_end, a.wi_target,
-            a.n_items, a.max_items, a.out, a.partial);
-}
-
 template <int RL, int VPL, int U, bool W, bool RS, int TAG>
 static void launch_seg(const SegArgs& a, hipStream_t s) {
     if (g_opt_nt_loads)
@@ -522,26 +427,12 @@ static void launch_seg(const SegArgs& a, hipStream_t s) {
         launch_seg3<RL, VPL, U, W, RS, false, TAG, 4, false>(a, s);
 }
 
-// tunable instantiations of the headline shape (1-KiB rows, no weights): A/B knobs
 template <int TAG>
-static void launch_seg_tuned(const SegArgs& a, hipStream_t s) {
-    const int u = g_opt_seg_unroll, w = g_opt_seg_wpb;
-    const bool x = g_opt_seg_xcd != 0, nt = g_opt_nt_loads != 0;
-#define HGNN_T(U_, W_)                                                                       \
-    do {                                                                                     \
-        if (nt && x) launch_seg3<64, 1, U_, false, false, true, TAG, W_, true>(a, s);        \
-        else if (nt) launch_seg3<64, 1, U_, false, false, true, TAG, W_, false>(a, s);       \
-        else if (x) launch_seg3<64, 1, U_, false, false, false, TAG, W_, true>(a, s);        \
-        else launch_seg3<64, 1, U_, false, false, false, TAG, W_, false>(a, s);              \
-    } while (0)
-    if (w == 8) {
-        if (u <= 4) HGNN_T(4, 8); else if (u <= 8) HGNN_T(8, 8); else HGNN_T(16, 8);
-    } else if (w == 16) {
-        if (u <= 4) HGNN_T(4, 16); else if (u <= 8) HGNN_T(8, 16); else HGNN_T(16, 16);
-    } else {
-        if (u <= 2) HGNN_T(2, 4); else if (u <= 4) HGNN_T(4, 4); else if (u <= 8) HGNN_T(8, 4); else HGNN_T(16, 4);
-    }
-#undef HGNN_T
+static void launch_seg_headline(const SegArgs& a, hipStream_t s) {
+    if (g_opt_nt_loads)
+        launch_seg3<64, 1, 16, false, false, true, TAG, 16, false>(a, s);
+    else
+        launch_seg3<64, 1, 16, false, false, false, TAG, 16, false>(a, s);
 }
 
 template <bool W, bool RS, int TAG>
@@ -557,19 +448,12 @@ static int dispatch_seg(const SegArgs& a, hipStream_t s) {
         return HGNN_OK;
     }
     const int nvec = F / 4;
-    if (g_opt_seg_grouped && nvec <= 32) {
-        if (nvec <= 4) launch_seg_grouped<4, 4, W, RS, TAG>(a, s);
-        else if (nvec <= 8) launch_seg_grouped<8, 8, W, RS, TAG>(a, s);
-        else if (nvec <= 16) launch_seg_grouped<16, 8, W, RS, TAG>(a, s);
-        else launch_seg_grouped<32, 8, W, RS, TAG>(a, s);
-        return HGNN_OK;
-    }
     if (nvec <= 4) launch_seg<4, 1, 4, W, RS, TAG>(a, s);
     else if (nvec <= 8) launch_seg<8, 1, 4, W, RS, TAG>(a, s);
     else if (nvec <= 16) launch_seg<16, 1, 4, W, RS, TAG>(a, s);
     else if (nvec <= 32) launch_seg<32, 1, 4, W, RS, TAG>(a, s);  // (U8 / 16-wave variants: within 1 %)
     else if (nvec <= 64) {
-        if (!W && !RS) launch_seg_tuned<TAG>(a, s);
+        if (!W && !RS) launch_seg_headline<TAG>(a, s);
         else launch_seg<64, 1, 8, W, RS, TAG>(a, s);
     } else if (nvec <= 128) launch_seg<64, 2, 4, W, RS, TAG>(a, s);
     else launch_seg<64, 4, 2, W, RS, TAG>(a, s);
@@ -591,17 +475,8 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     HGNN_REQUIRE(name != nullptr, "hgnn_set_option: name is NULL");
     if (!strcmp(name, "nt_loads")) g_opt_nt_loads = value;
     else if (!strcmp(name, "nt_stores")) g_opt_nt_stores = value;
-    else if (!strcmp(name, "seg_unroll")) g_opt_seg_unroll = value;
-    else if (!strcmp(name, "seg_wpb")) g_opt_seg_wpb = value;
-    else if (!strcmp(name, "seg_xcd")) g_opt_seg_xcd = value;
-    else if (!strcmp(name, "seg_grouped")) g_opt_seg_grouped = value;
     else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 31;
     else if (!strcmp(name, "mlp_split_variant")) g_opt_mlp_split_variant = value;
-    else if (!strcmp(name, "mlp_f32_waves")) g_opt_mlp_f32_waves = value;
-    else if (!strcmp(name, "mlp_split_shape")) g_opt_mlp_split_shape = value;
-    else if (!strcmp(name, "mlp_bf16_shape")) g_opt_mlp_bf16_shape = value;
-    else if (!strcmp(name, "mlp_bwd_shape")) g_opt_bwd_shape = value;
-    else if (!strcmp(name, "mlp_rows128")) g_opt_mlp_rows128 = value;
     else {
         set_error("hgnn_set_option: unknown option '%s'", name);
         return HGNN_ERR_INVALID_ARG;

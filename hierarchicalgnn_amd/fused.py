@@ -245,13 +245,6 @@ def _fragment_order(W: torch.Tensor) -> torch.Tensor:
     return W.view(F // 16, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
-def _fragment_order32(W: torch.Tensor) -> torch.Tensor:
-    """bf16 W[F, K] in the 32x32x16 MFMA A-fragment order (include/hgnn_hip.h, hgnn_mlp_forward_bf16_rows128):
-    [k16-step s][32-feature tile T][lane = 32*(k-half) + row][8 values]"""
-    F, K = W.shape
-    return W.view(F // 32, 32, K // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
-
-
 class _WeightCache:
     """prepared (re-laid-out / bf16 / split) copies of Linear weights, one per (weight object, layout).
 
@@ -329,27 +322,10 @@ def _prepared_weight(weight, order, kept_cols):
     return W
 
 
-def _rows128(widths, n_pre: int) -> bool:
-    """latent-256 bf16 MLPs (K -> 512 (-> 512) -> 256) run on the 128-rows-per-weight-fetch kernel
-    (hgnn_mlp_forward_bf16_rows128) after hgnn_set_option("mlp_rows128", 1) (A/B option: measured equal to the
-    feature-split kernel)"""
-    return (len(widths) in (2, 3) and widths[-1] == 256 and all(w == 512 for w in widths[:-1]) and n_pre == 0
-            and bool(_lib.load().hgnn_mlp_rows128_enabled()))
-
-
-def _rows128_desc(d) -> bool:
-    return _rows128([int(d.width[i + 1]) for i in range(int(d.n_layers))], int(d.n_pre))
-
-
 def _split_forward(d, out, dev):
     """launch the wide-layer bf16 kernel the descriptor's weights were laid out for"""
-    lib = _lib.load()
-    if _rows128_desc(d):
-        _lib.check(lib.hgnn_mlp_forward_bf16_rows128(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
-                   "hgnn_mlp_forward_bf16_rows128")
-    else:
-        _lib.check(lib.hgnn_mlp_forward_bf16_split(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
-                   "hgnn_mlp_forward_bf16_split")
+    _lib.check(_lib.load().hgnn_mlp_forward_bf16_split(ctypes.byref(d), _lib.ptr(out), _lib.current_stream(dev)),
+               "hgnn_mlp_forward_bf16_split")
 
 
 _fp32_split3 = os.environ.get("HGNN_FP32_SPLIT3", "1") != "0"
@@ -521,7 +497,7 @@ def _descriptor_bf16(net, segments, skip, split=False, dry=False):
     want_pre = _preproject_bf16
     if want_pre is None:
         widths = [lin.out_features for lin, _, _ in layers]
-        want_pre = len(layers) > 1 and lin0.out_features >= 512 and not _rows128(widths, 0)
+        want_pre = len(layers) > 1 and lin0.out_features >= 512
     proj = _projected_segments(segments, M) if (split and want_pre) else []
     col = n_kept = n_pre = 0
     kept_cols = []
@@ -556,8 +532,7 @@ def _descriptor_bf16(net, segments, skip, split=False, dry=False):
     d.n_layers = n
     d.width[0] = sum(c1 - c0 for c0, c1 in kept_cols)
     eps = None
-    order = _fragment_order32 if (split and _rows128([lin.out_features for lin, _, _ in layers], n_pre)) \
-        else _fragment_order
+    order = _fragment_order
     for l, (lin, ln, act) in enumerate(layers):
         if (l > 0 and lin.in_features != d.width[l]) or not lin.weight.is_cuda:
             return None

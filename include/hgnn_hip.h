@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 21
+#define HGNN_ABI_VERSION 22
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -101,28 +101,19 @@ const char* hgnn_last_error(void);
 int hgnn_sizeof_plan(void);
 int hgnn_sizeof_mlp_desc(void);
 
-/* Process-wide switches for A/B measurements:
- *   "nt_loads", "nt_stores", "seg_unroll", "seg_wpb", "seg_xcd"   K1..K6 launch shape / cache policy
- *   "seg_grouped"  rows of <= 128 floats: 0 (default) one work item per wave with a cross-group reduction,
- *                  1 one work item per row-covering lane group (64/RL destinations per wave; A/B: 2-5 % slower)
- *   "mlp_bf16_shape" bf16 MLP launch shape: 0 = 16 edges/wave, 2-deep weight ring; 1 (default) = 32
- *                  edges/wave, 3-deep ring for wide layers
- *   "mlp_f32_waves" fp32 fused MLP, L=256 two-layer kernel: 4 (default) or 8 waves per workgroup (A/B:
- *                  8 measured 3.6 % slower, bitwise equal)
- *   "mlp_split_shape" feature-split bf16 MLP: -1 (default) per shape, 0 = 4 waves x 64 rows, 1 = 8 waves
- *                  (L=256: x 128 rows; L=512: x 64 rows, the default there)
- *   "mlp_split_variant" schedule of the feature-split bf16 MLP: -1 (default) per shape, 0 counted
- *                  per-fragment waits, 2 one wait per k-chunk ("burst")
- *   "mlp_bwd_shape" fused bf16 backward layer, N = 512: 0 (default) 8 waves x 64 rows, 1 = 4 waves with the raw
- *                  z' tile reloaded per phase (A/B: spills, 6.2 vs 3.2 ms)
- *   "mlp_rows128"  bf16 MLPs of latent 256 (K -> 512 (-> 512) -> 256): 0 (default) the feature-split kernel, 1 =
- *                  hgnn_mlp_forward_bf16_rows128 (callers ask hgnn_mlp_rows128_enabled() to pick the weight layout;
- *                  A/B: half the L2 weight traffic, same time -- the phase-locked epilogues eat the gain)
- *   "mlp_ablate"   DIAGNOSTIC bits, results are WRONG.  fp32 / bf16 kernels: 1 skip LayerNorm/act,
- *                  2 skip weight DMA, 4 skip barriers (tools/tune_mlp.py); feature-split bf16
- *                  kernel: 1 weights from chunk 0 only, 2 skip LayerNorm/act, 4 load only the first
- *                  input panel, 8 skip the per-panel barriers, 16 LDS operand reads from chunk 0
- *                  only (tools/tune_mlp_split.py) */
+/* Process-wide switches (diagnostics / A-B measurements).  NOT THREAD-SAFE: plain static ints read at launch time;
+ * set them from the thread that launches, before the launches they should affect, never concurrently with one.
+ * The defaults are the measured-best variants; everything a round measured slower has been removed from the library
+ * (tools/experimental/ keeps the sources of the larger null results, DESIGN.md appendix A the numbers).
+ *   "nt_loads"     1 (default): non-temporal loads of once-read source rows in K1..K5
+ *   "nt_stores"    0 (default): non-temporal stores of gathered rows (K6)
+ *   "mlp_split_variant" schedule of the feature-split bf16 MLP: -1 (default) per shape, 0 counted per-fragment
+ *                  waits, 2 one wait per k-chunk ("burst")
+ *   "mlp_ablate"   DIAGNOSTIC bits, results are WRONG.  fp32 / bf16 kernels: 1 skip LayerNorm/act, 2 skip weight
+ *                  DMA, 4 skip barriers (tools/tune_mlp.py); feature-split bf16 kernel: 1 weights from chunk 0 only,
+ *                  2 skip LayerNorm/act, 4 load only the first input panel, 8 skip the per-panel barriers, 16 LDS
+ *                  operand reads from chunk 0 only (tools/tune_mlp_split.py)
+ * Any other name is an error (HGNN_ERR_INVALID_ARG). */
 int hgnn_set_option(const char* name, int value);
 
 /* Fills n_rows/n_dst/n_src/chunk/max_* of `plan` (pointers untouched).
@@ -328,19 +319,6 @@ int hgnn_mlp_forward_bf16(const hgnn_mlp_desc* d, void* out, hgnn_stream_t strea
  * forward of the bf16 training path. */
 int hgnn_mlp_supported_bf16_split(const hgnn_mlp_desc* d);
 int hgnn_mlp_forward_bf16_split(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
-
-/* bf16, latent 256 (K -> 512 (-> 512) -> 256, LayerNorm on every layer, every segment a multiple of 128 wide,
- * n_pre = 0): ONE persistent workgroup of 8 waves per CU owns 128 rows, wave w an eighth of every layer's features for
- * all 128 rows (v_mfma_f32_32x32x16_bf16), so a weight byte fetched from L2 serves 128 rows instead of the 64 of
- * hgnn_mlp_forward_bf16_split, which is L2-bandwidth bound on its weight stream.  Same descriptor and arithmetic
- * (gelu / tanh forms, fp32 LayerNorm, save_pre dumps as bf16 rows) as hgnn_mlp_forward_bf16_split, except the
- * weight layout: W[l] (bf16) in the 32x32x16 A-FRAGMENT ORDER,
- *   element index = ((s * (F/32) + T) * 64 + lane) * 8 + i  holds  W[32T + lane%32][16s + 8(lane/32) + i]
- * (F = out features, s = 16-wide k-step, T = 32-feature tile, lane = 0..63, i = 0..7).
- * hgnn_mlp_rows128_enabled: the "mlp_rows128" option (callers choose the weight layout by it). */
-int hgnn_mlp_supported_bf16_rows128(const hgnn_mlp_desc* d);
-int hgnn_mlp_forward_bf16_rows128(const hgnn_mlp_desc* d, void* out, hgnn_stream_t stream);
-int hgnn_mlp_rows128_enabled(void);
 
 /* fp32 rows, SPLIT-bf16 arithmetic (the Python layer's default path of the fp32 MLPs at latent 128 / 256: K -> 2L (-> 2L) -> L, and
  * K -> H -> H with H in {256, 512} = the two hidden layers of a score head, whose plain last Linear the caller applies;

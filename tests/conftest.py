@@ -89,10 +89,12 @@ def elem_err(a, b):
     return float((np.abs(a - b) / (np.abs(b) + rms)).max())
 
 
-def assert_parity(a, b, tol=1e-4, what=""):
-    """the fp32 parity bar, normwise AND element-wise"""
+def assert_parity(a, b, tol=1e-4, what="", elem_tol=None):
+    """the fp32 parity bar, normwise AND element-wise (``elem_tol``: a separate, stated element-wise bound for
+    quantities whose small elements are cancellation residue in ANY fp32 evaluation)"""
     a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
     b = b.detach().cpu().numpy() if hasattr(b, "detach") else np.asarray(b)
     assert a.shape == b.shape, (what, a.shape, b.shape)
     r, e = rel_err(a, b), elem_err(a, b)
-    assert r <= tol and e <= tol, f"{what}: normwise {r:.3g}, element-wise {e:.3g} > {tol:g}"
+    et = tol if elem_tol is None else elem_tol
+    assert r <= tol and e <= et, f"{what}: normwise {r:.3g} (bar {tol:g}), element-wise {e:.3g} (bar {et:g})"

@@ -78,24 +78,17 @@ def test_bf16_unsupported_width_is_an_error():
     # the feature-split kernel (wide layers; L = 512 is BASELINE config 4): ragged tails, 1..3 segments
     (128, 2, 3, 300, True), (256, 2, 3, 200, True), (512, 2, 3, 131, True), (128, 3, 3, 129, True),
     (256, 3, 2, 90, True), (512, 3, 2, 70, True), (256, 2, 1, 64, True), (256, 2, 3, 1, True),
-    # 128 rows x 8 waves launch shape of the same kernel (hgnn_set_option "mlp_split_shape" = 1)
-    (256, 2, 3, 333, "shape1"), (256, 2, 2, 128, "shape1"), (512, 2, 3, 131, "shape1"), (512, 3, 2, 70, "shape1"),
+    (256, 2, 3, 333, True), (256, 2, 2, 128, True),
+    # more tiles than resident workgroups
+    (256, 2, 3, 70001, True), (256, 3, 3, 40000, True),
     # pre-projected gathered segments in the bf16 split kernel (off by default: measured slower)
-    (256, 2, 3, 2000, "preproject"), (128, 2, 3, 1500, "preproject"),
-    # latent 256 on the 128-rows-per-weight-fetch kernel (hgnn_mlp_forward_bf16_rows128, option "mlp_rows128" = 1):
-    # one row, ragged tails, 1..3 segments, 3 layers, and more tiles than CUs (persistent loop + next-tile prefetch)
-    (256, 2, 3, 1, "rows128"), (256, 2, 3, 333, "rows128"), (256, 3, 2, 200, "rows128"), (256, 2, 1, 128, "rows128"),
-    (256, 2, 3, 70001, "rows128"), (256, 3, 3, 40000, "rows128")])
+    (256, 2, 3, 2000, "preproject"), (128, 2, 3, 1500, "preproject")])
 def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M, split):
     """bf16-MFMA fused MLP: against the fp32 oracle evaluated on the bf16-rounded inputs and weights"""
     from hierarchicalgnn_amd import _lib, fused, make_mlp
-    shape1 = split == "shape1"
-    rows128 = split == "rows128"
     fused._preproject_bf16 = split == "preproject"      # (forced on / off: the default decides by shape)
     split = bool(split)
     fused.set_bf16_split(split)
-    _lib.load().hgnn_set_option(b"mlp_split_shape", 1 if shape1 else 0)
-    _lib.load().hgnn_set_option(b"mlp_rows128", 1 if rows128 else 0)
     from oracle import hgnn_oracle as O
     g = torch.Generator().manual_seed(L * 10 + layers)
     out_act = "Tanh" if layers == 2 else "GELU"
@@ -120,15 +113,10 @@ def test_fused_mlp_bf16_vs_oracle(L, layers, nseg, M, split):
         with torch.no_grad():
             assert fused._wants_split(net, segs) == split
             assert fused.supported(net, segs, segs[-1][0])
-            if rows128:
-                desc = fused._descriptor_bf16(net, segs, segs[-1][0], True, dry=True)
-                assert fused._rows128_desc(desc[0]) and _lib.load().hgnn_mlp_supported_bf16_rows128(desc[0])
             out = fused.fused_concat_mlp(net, segs, segs[-1][0])
     finally:
         fused.set_bf16_split(True)
         fused._preproject_bf16 = None
-        _lib.load().hgnn_set_option(b"mlp_split_shape", -1)
-        _lib.load().hgnn_set_option(b"mlp_rows128", 0)
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
     # hidden activations are rounded to bf16 between layers: a few bf16 ulps at the output scale
     assert rel_err(out.float().cpu().numpy(), ref.numpy()) <= 4 * BF16_TOL

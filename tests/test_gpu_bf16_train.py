@@ -84,14 +84,9 @@ def _net(in_w, L, layers, out_act, seed):
 BF16_OUT, BF16_GRAD = 2e-2, 3e-2
 
 
-@pytest.mark.parametrize("L,layers", [(128, 2), (256, 2), (128, 3), (256, 3), (512, 2), (512, 3),
-                                      # forward + pre-LayerNorm dumps from hgnn_mlp_forward_bf16_rows128 ("mlp_rows128" = 1)
-                                      (256, -2), (256, -3)])
+@pytest.mark.parametrize("L,layers", [(128, 2), (256, 2), (128, 3), (256, 3), (512, 2), (512, 3)])
 def test_fused_train_bf16_matches_fp32_autograd(L, layers):
     from hierarchicalgnn_amd import _lib, fused, mlp
-    rows128 = layers < 0
-    layers = abs(layers)
-    _lib.load().hgnn_set_option(b"mlp_rows128", 1 if rows128 else 0)
     g = torch.Generator().manual_seed(L + layers)
     out_act = "Tanh" if layers == 2 else "GELU"
     net = _net(3 * L, L, layers, out_act, L).cuda()
@@ -118,10 +113,7 @@ def test_fused_train_bf16_matches_fp32_autograd(L, layers):
         return out.detach().float(), t.grad.float(), d.grad.float(), [p.grad.clone() for p in net.parameters()]
 
     o_ref, gt_ref, gd_ref, gp_ref = run(False)
-    try:
-        o, gt, gd, gp = run(True)
-    finally:
-        _lib.load().hgnn_set_option(b"mlp_rows128", 0)
+    o, gt, gd, gp = run(True)
     assert rel_err(o.cpu().numpy(), o_ref.cpu().numpy()) <= BF16_OUT
     assert rel_err(gt.cpu().numpy(), gt_ref.cpu().numpy()) <= BF16_GRAD
     assert rel_err(gd.cpu().numpy(), gd_ref.cpu().numpy()) <= BF16_GRAD

@@ -387,32 +387,6 @@ def test_randomized_shapes_against_oracle(H, O):
                 assert rel_err(wd.grad.cpu().numpy(), w_ref.grad.numpy()) <= TOL, tag
 
 
-def test_grouped_narrow_row_kernel_option(H, O):
-    """hgnn_set_option("seg_grouped", 1): one work item per row-covering lane group (the round-2 A/B variant for
-    rows of <= 128 floats; slower, hence off by default) gives the same sums, weighted and gathered forms included"""
-    from hierarchicalgnn_amd import _lib
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(77)
-    try:
-        _lib.check(lib.hgnn_set_option(b"seg_grouped", 1))
-        for F in (4, 24, 32, 64, 100, 128):
-            N, M = 900, 15000
-            idx = torch.randint(0, N, (M,), generator=g)
-            idx[:2000] = idx[:2000] % 3                       # long lists: split work items + partial rows
-            src = torch.randn(M, F, generator=g)
-            w = torch.rand(M, 1, generator=g)
-            out = H.scatter_add(src.cuda(), idx.cuda(), dim=0, dim_size=N)
-            assert rel_err(out.cpu().numpy(), O.scatter_add(src, idx, 0, N).numpy()) <= 1e-5, F
-            out = H.scatter_add(src.cuda(), idx.cuda(), dim=0, dim_size=N, weight=w.cuda())
-            assert rel_err(out.cpu().numpy(), O.scatter_add(src * w, idx, 0, N).numpy()) <= 1e-5, F
-            tab = torch.randn(300, F, generator=g)
-            gi = torch.randint(0, 300, (M,), generator=g)
-            out = H.gather_scale_scatter(tab.cuda(), gi.cuda(), idx.cuda(), N, w.cuda())
-            assert rel_err(out.cpu().numpy(), O.scatter_add(tab[gi] * w, idx, 0, N).numpy()) <= 1e-5, F
-    finally:
-        _lib.check(lib.hgnn_set_option(b"seg_grouped", 0))
-
-
 def test_inference_tensor_index_refilled_in_place_is_never_served_from_a_cache(H):
     """an index created under torch.inference_mode() has no version counter but CAN be overwritten in place there (a
     static edge_index buffer refilled per event): plans / int32 copies / derived tensors must follow the contents"""

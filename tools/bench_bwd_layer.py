@@ -43,10 +43,7 @@ for K, N in ((256, 512), (128, 256), (512, 512)):
         return dzp, a
 
     r = {"unfused_ms": t(unfused)}
-    for shape in ((0, 1) if N == 512 else (0,)):
-        lib.hgnn_set_option(b"mlp_bwd_shape", shape)
-        r["fused_8_waves_ms" if shape == 0 else "fused_4_waves_reload_ms"] = t(lambda: fused._bwd_layer(dz, W, z, gm, bt, 1, 1e-5, want_a=True))
-    lib.hgnn_set_option(b"mlp_bwd_shape", 0)
+    r["fused_ms"] = t(lambda: fused._bwd_layer(dz, W, z, gm, bt, 1, 1e-5, want_a=True))
     out[f"ln_form_K{K}_N{N}"] = r
     del dz, z
 for K, N in ((512, 256), (256, 128)):

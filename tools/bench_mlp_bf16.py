@@ -51,7 +51,6 @@ with torch.no_grad():
     lib = _lib.load()
     if L <= 256:
         fused.set_bf16_split(False)
-        lib.hgnn_set_option(b"mlp_bf16_shape", 1)
         t = timeit(lambda: mlp.concat_mlp(net, seg16, skip=edges16))
         res["bf16_fused_wave_owns_all_features_ms"] = t
         fused.set_bf16_split(True)

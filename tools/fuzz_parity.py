@@ -128,20 +128,14 @@ for case in range(n_cases):
             out = mlp.concat_mlp(net, segs16, skip=segs16[2][0]).float()
         note("fused_mlp_bf16_vs_fp32", rel(out, ref), 3e-2, (L, layers, Mm, n_tab))
         if L >= 128:
-            # second session of round 2: pre-projected node segments (whole-row LDS-DMA gather) forced on / off, and
-            # the 128-rows-per-weight-fetch kernel (latent 256)
-            from hierarchicalgnn_amd import _lib
-            for name, pre, r128 in (("preproject_on", True, 0), ("preproject_off", False, 0), ("rows128", False, 1)):
-                if r128 and L != 256:
-                    continue
+            # second session of round 2: pre-projected node segments (whole-row LDS-DMA gather) forced on / off
+            for name, pre in (("preproject_on", True), ("preproject_off", False)):
                 fused._preproject_bf16 = pre
-                _lib.load().hgnn_set_option(b"mlp_rows128", r128)
                 try:
                     with torch.no_grad():
                         o2 = mlp.concat_mlp(net, segs16, skip=segs16[2][0]).float()
                 finally:
                     fused._preproject_bf16 = None
-                    _lib.load().hgnn_set_option(b"mlp_rows128", 0)
                 note("fused_mlp_bf16_" + name + "_vs_fp32", rel(o2, ref), 3e-2, (L, layers, Mm, n_tab))
 
     # ---------------- round 2: bf16 training kernels (weight gradient, fused backward layer, training gradients)

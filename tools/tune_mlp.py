@@ -39,24 +39,6 @@ with torch.no_grad():
             torch.cuda.synchronize()
             times[v].append(s.elapsed_time(e) / 3)
 _lib.check(lib.hgnn_set_option(b"mlp_ablate", 0))
-if L == 256:
-    # 8 waves per workgroup (128 rows, one workgroup per CU): same arithmetic per row, bitwise equal
-    t8, t4 = [], []
-    with torch.no_grad():
-        for rnd in range(4):
-            for waves, acc in ((8, t8), (4, t4)):
-                _lib.check(lib.hgnn_set_option(b"mlp_f32_waves", waves))
-                out = cell._edge_update(nodes, edges, graph)
-                assert torch.equal(out, ref)
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                for _ in range(3):
-                    cell._edge_update(nodes, edges, graph)
-                e.record()
-                torch.cuda.synchronize()
-                acc.append(s.elapsed_time(e) / 3)
-    _lib.check(lib.hgnn_set_option(b"mlp_f32_waves", 4))
-    print(f"8 waves / workgroup   : median {sorted(t8)[2]:.3f} ms   (4 waves in the same rounds: {sorted(t4)[2]:.3f} ms)")
 for name, v in variants:
     t = sorted(times[v])
     print(f"{name:22s}: median {t[len(t)//2]:.3f} ms  min {t[0]:.3f} ms  {flop/t[len(t)//2]/1e9:.1f} TF/s")

@@ -42,16 +42,9 @@ def timeit(fn, reps=5):
 res = {"L": L, "M": M}
 try:
     with torch.no_grad():
-        lib.hgnn_set_option(b"mlp_split_shape", 0)
         for var in (0, 2, 0, 2):
             lib.hgnn_set_option(b"mlp_split_variant", var)
             res.setdefault(f"variant{var}_ms", []).append(timeit(lambda: mlp.concat_mlp(net, seg, skip=edges)))
-        if L in (256, 512):
-            lib.hgnn_set_option(b"mlp_split_shape", 1)
-            for var in (0, 2, 0, 2):
-                lib.hgnn_set_option(b"mlp_split_variant", var)
-                res.setdefault(f"shape1_8waves_variant{var}_ms", []).append(timeit(lambda: mlp.concat_mlp(net, seg, skip=edges)))
-        lib.hgnn_set_option(b"mlp_split_shape", int(os.environ.get("SPLIT_SHAPE", "-1")))
         lib.hgnn_set_option(b"mlp_split_variant", int(os.environ.get("SPLIT_VARIANT", "-1")))
         if os.environ.get("SPLIT_AB_ONLY"):
             print(json.dumps(res, indent=1)); raise SystemExit(0)
@@ -66,6 +59,5 @@ try:
 finally:
     lib.hgnn_set_option(b"mlp_ablate", 0)
     lib.hgnn_set_option(b"mlp_split_variant", -1)
-    lib.hgnn_set_option(b"mlp_split_shape", -1)
 res["full_tflops"] = flop / res["full_ms"] / 1e9
 print(json.dumps(res, indent=1))
