@@ -359,7 +359,29 @@ def set_fp32_split3(flag: bool) -> None:
     _fp32_split3 = bool(flag)
 
 
+_training_forward_depth = 0
+
+
+class training_forward:
+    """context: the enclosed no-grad evaluation belongs to a TRAINING step (the first pass of a reentrant
+    ``torch.utils.checkpoint`` segment, gnn_utils._maybe_checkpoint).  The split-bf16 evaluation of the fp32 MLPs is an
+    INFERENCE default; inside this context a no-grad forward uses exactly what the recompute under autograd will use
+    (the exact fp32 kernels, or split-bf16 everywhere with set_fp32_split3_training(True)): forward values and the
+    point the gradients are taken at agree bitwise, as with the reference's own recompute."""
+
+    def __enter__(self):
+        global _training_forward_depth
+        _training_forward_depth += 1
+
+    def __exit__(self, *exc):
+        global _training_forward_depth
+        _training_forward_depth -= 1
+        return False
+
+
 def _split3_on(net) -> bool:
+    if _training_forward_depth > 0 and not _fp32_split3_train:
+        return False
     flag = getattr(net, "_hgnn_split3", None)      # per-module override (hparams["fp32_gemm"])
     return _fp32_split3 if flag is None else bool(flag)
 

@@ -32,7 +32,12 @@ from .utils import make_mlp
 
 def _maybe_checkpoint(enabled, fn, *args):
     if enabled and torch.is_grad_enabled() and any(torch.is_tensor(a) and a.requires_grad for a in args):
-        return checkpoint(fn, *args, use_reentrant=True)
+        # the no-grad first pass of a reentrant checkpoint is PART OF A TRAINING STEP: it must use the arithmetic its
+        # backward-time recompute will use (bitwise-deterministic recompute), so the inference-only
+        # split-bf16 evaluation of the fp32 MLPs is held off while it runs (fused.training_forward)
+        from . import fused
+        with fused.training_forward():
+            return checkpoint(fn, *args, use_reentrant=True)
     return fn(*args)
 
 

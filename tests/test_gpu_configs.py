@@ -48,8 +48,11 @@ def _sketch_close(model, z, tol=TOL):
     for i, n in enumerate(names):
         cnt = params[n].numel()
         abssum = max(ref[i, 1], 1e-30)
-        assert abs(got[i, 1] - ref[i, 1]) <= tol * abssum, (n, got[i], ref[i])
-        slack = 5 * tol * abssum / np.sqrt(cnt) + 1e-7 * abssum
+        # absolute floor 1e-6: a gradient that is analytically ZERO (the bias of the BatchNorm in front of a
+        # mean-normalised exp weight, gnn_utils.py:209-213: exp(bias) cancels in w / mean(w)) is rounding residue in
+        # every fp32 evaluation -- 7e-10 in the reference's, 3e-8 in ours, against neighbours of order 1..1e4
+        assert abs(got[i, 1] - ref[i, 1]) <= tol * abssum + 1e-6, (n, got[i], ref[i])
+        slack = 5 * tol * abssum / np.sqrt(cnt) + 1e-7 * abssum + 1e-6
         assert abs(got[i, 0] - ref[i, 0]) <= slack, (n, got[i], ref[i])
         assert abs(got[i, 2] - ref[i, 2]) <= slack, (n, got[i], ref[i])
 
@@ -80,7 +83,6 @@ def test_config2_ec_in_latent128_forward_and_backward():
     _sketch_close(model, z)
 
 
-@pytest.mark.both_fp32_gemms
 def test_config3_hgnn_cell_latent256_forward_and_backward():
     import hierarchicalgnn_amd as H
     z = load_golden("hgnn_cell_L256.npz")
@@ -147,14 +149,15 @@ def test_config3_bc_hgnn_gmm_fp32(latent):
     assert np.abs(scores.cpu().numpy() - z["bipartite_scores"]).max() <= TOL
 
 
-@pytest.mark.both_fp32_gemms
 def test_config3_bc_training_step_against_the_reference_gradients():
     """config 3 TRAINS: the reference's own BC_HierarchicalGNN_GMM (HGNN_GMM.yaml, latent 256, 25,299,957 parameters)
     in train() mode, forward with autograd + backward of  (scores * r).sum() + c * (emb * emb.roll(1, 0)).sum()
     (bipartite_classification_base.py:194-200 -> HGNN_GMM.py:323-346; fixture: make_golden.gen_bc_hgnn_backward).
     The HIP path replays it through BC_MessagePassing.embed -> hierarchy_from_clusters (the captured discrete
     decision: cluster labels, kNN topologies) -> hgnn_block -> score, in training mode (batch-statistics BatchNorm,
-    reentrant checkpointing), and is held to the reference's gradients at 1e-4, normwise and element-wise."""
+    reentrant checkpointing), and is held to the reference's gradients at 1e-4, normwise and element-wise.  (A training
+    step runs the exact fp32 kernels in BOTH passes of every checkpoint segment -- fused.training_forward -- whatever
+    the inference default is; the opt-in all-split-bf16 training path is covered in tests/test_gpu_split3.py.)"""
     from hierarchicalgnn_amd import fused
     from hierarchicalgnn_amd.models import BC_MessagePassing
     z = load_golden("bc_hgnn_train_L256.npz")

@@ -310,3 +310,38 @@ def test_full_size_ab_bc_latent256_split_vs_exact():
     d = (split[3] - exact[3]).abs()
     assert float(exact[3].std()) > 1e-3
     assert float(d.max()) <= AB_BOUND, float(d.max())
+
+
+def test_checkpointed_training_forward_is_bitwise_deterministic_and_exact_by_default():
+    """The split-bf16 evaluation is an INFERENCE default.  Inside a training step (the no-grad first pass of a reentrant
+    checkpoint segment and its recompute under autograd) the default arithmetic is the exact fp32 kernels in BOTH
+    passes: the cell's training-mode outputs equal, bit for bit, the outputs of the exact kernels, and no split-bf16
+    launch happens -- while a plain no-grad call of the same cell does use split-bf16."""
+    import hierarchicalgnn_amd as H
+    from hierarchicalgnn_amd import fused, synth
+    assert not fused._fp32_split3_train
+    old = fused._fp32_split3
+    fused.set_fp32_split3(True)
+    try:
+        torch.manual_seed(2)
+        L = 128
+        hp = dict(latent=L, hidden=2 * L, nb_edge_layer=2, nb_node_layer=3, layernorm=True, hidden_activation="GELU")
+        cell = H.InteractionGNNCell(hp).cuda()
+        x, ei = synth.trackml_event(3000, 20000, seed=4)
+        graph = synth.directed(ei).cuda()
+        nodes = torch.randn(3000, L, device="cuda")
+        edges = torch.randn(graph.shape[1], L, device="cuda")
+        n0 = fused.stats.get("split3_calls", 0)
+        n_g, e_g = nodes.clone().requires_grad_(True), edges.clone().requires_grad_(True)
+        on, oe = cell(n_g, e_g, graph)                       # training mode: two checkpointed segments
+        (on.sum() + oe.sum()).backward()
+        assert fused.stats.get("split3_calls", 0) == n0      # no split-bf16 launch inside the training step
+        with torch.no_grad():
+            sn, se = cell(nodes, edges, graph)               # inference: the split-bf16 default
+            assert fused.stats.get("split3_calls", 0) > n0
+            fused.set_fp32_split3(False)
+            xn, xe = cell(nodes, edges, graph)               # inference on the exact kernels
+        assert torch.equal(on.detach(), xn) and torch.equal(oe.detach(), xe)
+        assert not torch.equal(se, xe) and float((se - xe).abs().max()) < 1e-4
+    finally:
+        fused.set_fp32_split3(old)
