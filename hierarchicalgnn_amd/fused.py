@@ -107,9 +107,11 @@ def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
     return out
 
 
-def _descriptor(net, segments, skip, dry=False):
+def _descriptor(net, segments, skip, dry=False, split_proj=False):
     """(descriptor, keep-alive list, M, n_out) for hgnn_mlp_forward_f32, or None.  ``dry``: only decide
-    supportability (no projection GEMMs are run; the descriptor must not be launched)."""
+    supportability (no projection GEMMs are run; the descriptor must not be launched).  ``split_proj``: the caller will
+    run the split-bf16 kernel on this descriptor: the N-row projection GEMMs of the gathered segments use the same
+    arithmetic (hgnn_linear_f32_split3, four products) instead of the library's fp32 GEMM."""
     layers = _parse(net)
     if layers is None or len(layers) not in (1, 2, 3) or not (1 <= len(segments) <= 3):
         return None
@@ -146,8 +148,10 @@ def _descriptor(net, segments, skip, dry=False):
             if dry:
                 P = t
             else:
-                with torch.autocast("cuda", enabled=False):   # the kernel reads P as fp32
-                    P = torch.matmul(t.detach(), lin0.weight.detach()[:, col:col + w].t())   # [rows, H]
+                P = _split3_project(t.detach(), lin0.weight, (col, col + w)) if split_proj else None
+                if P is None:
+                    with torch.autocast("cuda", enabled=False):   # the kernel reads P as fp32
+                        P = torch.matmul(t.detach(), lin0.weight.detach()[:, col:col + w].t())   # [rows, H]
                 keep.append(P)
             d.pre_table[n_pre] = P.data_ptr()
             d.pre_index[n_pre] = i32.data_ptr() if i32.numel() else None
@@ -427,6 +431,24 @@ def _split3_linear(x: torch.Tensor, weight, cols, net) -> Optional[torch.Tensor]
                                                       _lib.ptr(out), _lib.current_stream(x.device)),
                    "hgnn_linear_f32_split3")
     stats["split3_linear_calls"] = stats.get("split3_linear_calls", 0) + 1
+    return out
+
+
+def _split3_project(table: torch.Tensor, weight, cols) -> Optional[torch.Tensor]:
+    """table [R, w] . W[:, cols]^T -> [R, H]: the pre-projection of a gathered segment (``_projected_segments``) in
+    split-bf16 arithmetic (four products), or None when the shape has no instantiation"""
+    R, K = int(table.shape[0]), int(table.shape[1])
+    N = int(weight.shape[0])
+    if R == 0 or K % 128 or N not in (256, 512) or table.dtype != torch.float32 or not table.is_cuda:
+        return None
+    # the kernel wants the weight of the Linear that maps K -> N: W[:, cols]  [N, K]
+    Wv = _split3_weight(weight, (tuple(cols),), False)
+    tc = table if table.is_contiguous() else table.contiguous()
+    out = torch.empty((R, N), dtype=torch.float32, device=table.device)
+    with torch.cuda.device(table.device):
+        _lib.check(_lib.load().hgnn_linear_f32_split3(_lib.ptr(tc), R, K, _lib.ptr(Wv), N, None, _lib.ptr(out),
+                                                      _lib.current_stream(table.device)), "hgnn_linear_f32_split3")
+    stats["split3_project_calls"] = stats.get("split3_project_calls", 0) + 1
     return out
 
 
@@ -735,7 +757,8 @@ def fused_concat_mlp(net, segments, skip: Optional[torch.Tensor], out: Optional[
                     segs = [(out_c, None)]
             return out_c if out is None else out.copy_(out_c)
     split = bf16 and _wants_split(net, segments)
-    desc = _descriptor_bf16(net, segments, skip, split) if bf16 else _descriptor(net, segments, skip)
+    desc = _descriptor_bf16(net, segments, skip, split) if bf16 else \
+        _descriptor(net, segments, skip, split_proj=_split3_applies(net, segments))
     if desc is None:
         raise RuntimeError("fused_concat_mlp: unsupported arguments (call supported() first)")
     d, keep, M, n_out = desc
