@@ -549,8 +549,9 @@ extern "C" int hgnn_mlp_forward_f32(const hgnn_mlp_desc* d, float* out, hgnn_str
         a.save_pre[l] = l < d->n_layers ? d->save_pre[l] : nullptr;
         HGNN_REQUIRE((uintptr_t)a.save_pre[l] % 16 == 0, "hgnn_mlp_forward_f32: save_pre[%d] must be 16-byte aligned", l);
     }
-    HGNN_REQUIRE(!(is_head(d) && (d->save_pre[0] || d->save_pre[1] || d->save_pre[2])),
-                 "hgnn_mlp_forward_f32: save_pre is not available for heads");
+    // heads: the two LayerNorm'ed hidden layers can dump (training forward of the score heads); the plain last layer's
+    // "pre-LayerNorm output" is the result itself
+    HGNN_REQUIRE(!(is_head(d) && d->save_pre[2]), "hgnn_mlp_forward_f32: save_pre[2] is not available for heads");
     a.eps = d->ln_eps;
     a.skip = d->skip;
     a.out = out;

@@ -872,6 +872,10 @@ class _FusedMLPTrain(torch.autograd.Function):
             raise RuntimeError("fused_concat_mlp_train: unsupported arguments (call supported_train() first)")
         d, keep, M, n_out = desc
         n = int(d.n_layers)
+        head = int(d.w_last_rows) == 32 and _parse(net)[-1][1] is None
+        if head:
+            n -= 1             # a score head: the LayerNorm'ed hidden layers are differentiated here, the plain last
+                               # Linear is applied by the caller on the returned hidden rows (``fused_head_train``)
         dev = tables[0].device
         zs = [torch.empty((M, int(d.width[l + 1])), dtype=torch.float32, device=dev) for l in range(n)]
         for l in range(n):
@@ -879,7 +883,7 @@ class _FusedMLPTrain(torch.autograd.Function):
         out = torch.empty((M, n_out), dtype=torch.float32, device=dev)
         if M:
             with torch.cuda.device(dev):
-                if _try_split3(net, segments, d, keep, training=True):
+                if not head and _try_split3(net, segments, d, keep, training=True):
                     # opt-in: the forward (and its dumps) on the split-bf16 kernel; the backward below is unchanged
                     _lib.check(_lib.load().hgnn_mlp_forward_f32_split3(ctypes.byref(d), _lib.ptr(out),
                                                                        _lib.current_stream(dev)),
@@ -895,6 +899,10 @@ class _FusedMLPTrain(torch.autograd.Function):
         ctx.acts = [int(d.act[l]) for l in range(n)]
         ctx.eps = float(d.ln_eps)
         ctx.save_for_backward(*tables, *params, *zs)
+        if head:
+            # the hidden rows feeding the plain last Linear: one LayerNorm / activation row pass over the last dump
+            lays = _parse(net)
+            return _ln_act_forward(zs[n - 1], lays[n - 1][1].weight, lays[n - 1][1].bias, ctx.acts[n - 1], ctx.eps)
         return out
 
     @staticmethod
@@ -915,7 +923,7 @@ class _FusedMLPTrain(torch.autograd.Function):
         if int(grad_out.shape[0]) == 0:
             return _zero_grads(ctx, tables, params, grad_out, n_seg)
         W = [params[4 * l] for l in range(n)]
-        lw = [lin.weight for lin, _, _ in _parse(ctx.net)]   # the Parameter objects themselves (weight-prep cache keys)
+        lw = [lin.weight for lin, _, _ in _parse(ctx.net)][:n]   # the Parameter objects themselves (weight-prep cache keys)
         lnw = [params[4 * l + 2] for l in range(n)]
         lnb = [params[4 * l + 3] for l in range(n)]
         aten = torch.ops.aten
@@ -1024,15 +1032,36 @@ def supported_train(net, segments, skip) -> bool:
     if desc is None:
         return False
     d = desc[0]
-    # heads / narrow encoders (zero-padded last layer) have no dumps; the small-K encoders (w0_cols = 16: the
-    # kernel-side zero padding of W[0]) do -- their backward uses the unpadded parameters
-    if int(d.w_last_rows) != 0:
+    # narrow encoders (zero-padded LayerNorm'ed last layer) have no dumps; the small-K encoders (w0_cols = 16: the
+    # kernel-side zero padding of W[0]) do -- their backward uses the unpadded parameters; score heads (plain last
+    # layer stored as 32 rows) dump their two hidden layers (``fused_head_train``)
+    if int(d.w_last_rows) != 0 and not _is_head(net):
         return False
+    if _is_head(net) and (skip is not None or any(int(d.width[l + 1]) not in (64, 128, 256, 512) for l in range(2))):
+        return False                                   # widths of the LayerNorm / activation row kernels
     return bool(_lib.load().hgnn_mlp_supported(ctypes.byref(d)))
+
+
+def _is_head(net) -> bool:
+    layers = _parse(net)
+    return layers is not None and len(layers) == 3 and layers[2][1] is None and layers[0][1] is not None \
+        and layers[1][1] is not None and layers[2][0].out_features <= 32
 
 
 def fused_concat_mlp_train(net, segments, skip: Optional[torch.Tensor]):
     layers = _parse(net)
+    if not _is_bf16(segments) and _is_head(net):
+        # score heads (IN.py:107-115,126-127; HGNN_GMM.py:313-321,342-344) under autograd: the two LayerNorm'ed hidden
+        # layers on the differentiable fused kernel (dumps + hand-written backward), the plain last Linear -- an
+        # [M, H] x [H, w<=32] product -- applied to the returned hidden rows
+        body = layers[:2]
+        params = []
+        for lin, ln, _ in body:
+            params += [lin.weight, lin.bias, ln.weight, ln.bias]
+        hidden = _FusedMLPTrain.apply(net, tuple(i for _, i in segments), False, *[t for t, _ in segments], *params)
+        last = layers[2][0]
+        stats["fused_head_train_calls"] = stats.get("fused_head_train_calls", 0) + 1
+        return torch.nn.functional.linear(hidden, last.weight, last.bias)
     params = []
     for lin, ln, _ in layers:
         params += [lin.weight, lin.bias, ln.weight, ln.bias]

@@ -187,6 +187,49 @@ def test_fused_heads_width_one(L, act):
     assert rel_err(out.cpu().numpy(), ref.numpy()) <= TOL
 
 
+@pytest.mark.parametrize("L,act,M", [(32, "GELU", 777), (128, "Tanh", 1500), (256, "Tanh", 400), (128, "GELU", 0)])
+def test_fused_heads_width_one_under_autograd(L, act, M):
+    """the score heads in a TRAINING step (IN.py:126-127, HGNN_GMM.py:342-344 under autograd): the two LayerNorm'ed
+    hidden layers on the differentiable fused kernel (pre-LayerNorm dumps + hand-written backward), the plain last
+    Linear trailing -- outputs and every gradient against autograd through the nn.Sequential itself"""
+    from hierarchicalgnn_amd import fused, make_mlp, mlp
+    g = torch.Generator().manual_seed(L + 11)
+    torch.manual_seed(L + 1)
+    net = make_mlp(2 * L, 2 * L, 1, 3, layer_norm=True, output_activation=None, hidden_activation=act).cuda()
+    for p in net.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.2 * torch.randn_like(p))
+    a0 = torch.randn(M, L, generator=g).cuda()
+    tab0 = torch.randn(60, L, generator=g).cuda()
+    idx = torch.randint(0, 60, (M,), generator=g).cuda()
+    r = torch.randn(M, 1, generator=g).cuda()
+
+    def run(use_fused):
+        for p in net.parameters():
+            p.grad = None
+        a, tab = a0.clone().requires_grad_(True), tab0.clone().requires_grad_(True)
+        if use_fused:
+            n0, h0 = fused.stats["fused_train_calls"], fused.stats.get("fused_head_train_calls", 0)
+            out = mlp.concat_mlp(net, [(a, None), (tab, idx)])
+            assert fused.stats["fused_train_calls"] == n0 + 1 and fused.stats["fused_head_train_calls"] == h0 + 1
+        else:
+            out = net(torch.cat([a, tab[idx]], dim=1))
+        (out * r).sum().backward()
+        return out.detach(), a.grad, tab.grad, [p.grad.clone() for p in net.parameters()]
+
+    o, ga, gt, gp = run(True)
+    o_ref, ga_ref, gt_ref, gp_ref = run(False)
+    assert o.shape == (M, 1)
+    if M == 0:
+        assert all(float(x.abs().max()) == 0.0 for x in gp[:8])
+        return
+    assert rel_err(o.cpu().numpy(), o_ref.cpu().numpy()) <= TOL
+    assert rel_err(ga.cpu().numpy(), ga_ref.cpu().numpy()) <= TOL
+    assert rel_err(gt.cpu().numpy(), gt_ref.cpu().numpy()) <= TOL
+    for (name, _), x, y in zip(net.named_parameters(), gp, gp_ref):
+        assert rel_err(x.cpu().numpy(), y.cpu().numpy()) <= TOL, name
+
+
 @pytest.mark.parametrize("L,layers", [(32, 2), (128, 2), (64, 3), (256, 2), (256, 3)])
 def test_fused_train_backward_matches_autograd(L, layers):
     """differentiable fused MLP (kernel forward with pre-LN dumps + hand-written backward) against
