@@ -65,10 +65,15 @@ __device__ __forceinline__ void split4(const f32x4 v, u16x4& h, u16x4& m) {
 }
 
 // bias -> LayerNorm over ALL features of the layer -> activation (exact-erf GELU: this is the fp32 parity path)
-template <int NT, int NW>
+// ACT >= 0: the activation code is a compile-time constant (a runtime switch compiles to a scalar branch tree PER
+// ELEMENT -- ~600 branches per tile and wave, every element its own basic block, no overlap between the
+// transcendental chains of neighbouring elements: PMC showed 3.9k vector instructions and 19 % VALU-active wave time
+// per tile against 768 MFMAs); ACT = -1 keeps the runtime code for the rare combinations
+template <int NT, int NW, int ACT>
 __device__ __forceinline__ void layernorm_act(f32x4 (&acc)[NT][NJ], const float* __restrict__ lnw,
-                                              const float* __restrict__ lnb, int act, float eps, float* red, int wave,
+                                              const float* __restrict__ lnb, int act_rt, float eps, float* red, int wave,
                                               int ei, int g) {
+    const int act = ACT >= 0 ? ACT : act_rt;
     constexpr float inv_n = 1.0f / (float)(NW * NT * 16);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -225,7 +230,7 @@ __device__ __forceinline__ void gemm3s(f32x4 (&acc)[NT][NJ], const u16x8* __rest
 // NW waves share the 64 rows (8: two per SIMD; 16: four per SIMD -- at latent 256 the two bf16 planes of the hidden
 // rows leave room for ONE workgroup per CU, whose waves are phase-locked by the barriers: more of them hide more
 // latency); NTH / NTO: 16-feature tiles per wave of the hidden / output layers; NL = 2 or 3 layers
-template <int NW, int NTH, int NTO, int NL>
+template <int NW, int NTH, int NTO, int NL, int ACT_H, int ACT_O>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = NW * 64;
@@ -398,8 +403,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
             }
         }
         dump_pre<NTH, H>(acc1, a.save_pre[0], a.M, e0, wave, ei, g);
-        layernorm_act<NTH, NW>(acc1, a.lnw[0] + wave * NTH * 16 + 4 * g, a.lnb[0] + wave * NTH * 16 + 4 * g, a.act[0], a.eps,
-                               red, wave, ei, g);
+        layernorm_act<NTH, NW, ACT_H>(acc1, a.lnw[0] + wave * NTH * 16 + 4 * g, a.lnb[0] + wave * NTH * 16 + 4 * g, a.act[0],
+                                      a.eps, red, wave, ei, g);
         // (the barrier inside layernorm_act also means: every wave is done reading the panels)
         write_hidden2<NTH, HRS, PLB>(acc1, smem, wave, ei, g);
         __syncthreads();
@@ -412,8 +417,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
                 gemm3s<NTH, HRS, NW>(acc1, wp1, 0, 2 * NC, hlane, hlane + PLB, NC);
             }
             dump_pre<NTH, H>(acc1, a.save_pre[1], a.M, e0, wave, ei, g);
-            layernorm_act<NTH, NW>(acc1, a.lnw[1] + wave * NTH * 16 + 4 * g, a.lnb[1] + wave * NTH * 16 + 4 * g, a.act[1],
-                                   a.eps, red, wave, ei, g);
+            layernorm_act<NTH, NW, ACT_H>(acc1, a.lnw[1] + wave * NTH * 16 + 4 * g, a.lnb[1] + wave * NTH * 16 + 4 * g,
+                                          a.act[1], a.eps, red, wave, ei, g);
             write_hidden2<NTH, HRS, PLB>(acc1, smem, wave, ei, g);   // (barrier inside layernorm_act: all reads done)
             __syncthreads();
         }
@@ -447,8 +452,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
                 for (int t = 0; t < NTO; ++t) sk[t][j] = *(const f32x4*)(a.skip + off[j] + t * 16);
             }
         }
-        layernorm_act<NTO, NW>(acc2, a.lnw[LO] + wave * NTO * 16 + 4 * g, a.lnb[LO] + wave * NTO * 16 + 4 * g, a.act[LO],
-                               a.eps, red, wave, ei, g);
+        layernorm_act<NTO, NW, ACT_O>(acc2, a.lnw[LO] + wave * NTO * 16 + 4 * g, a.lnb[LO] + wave * NTO * 16 + 4 * g, a.act[LO],
+                                      a.eps, red, wave, ei, g);
         // (the barrier inside: every wave is past the hidden planes, the next tile's indices are visible)
         if (has_next && npass > 0) {
             pissue(0, ti_next);
@@ -560,8 +565,8 @@ static int launch_linear(const float* x, int K, const unsigned short* W, const f
 
 static int g_cus = 0;
 
-template <int NW, int NTH, int NTO, int NL>
-static int launch(const Args& a, hipStream_t s) {
+template <int NW, int NTH, int NTO, int NL, int ACT_H, int ACT_O>
+static int launch_act(const Args& a, hipStream_t s) {
     constexpr int NTHR = NW * 64;
     constexpr int H = NTH * NW * 16;
     constexpr int HRS = H * 2 + 16;
@@ -577,11 +582,28 @@ static int launch(const Args& a, hipStream_t s) {
     const long long n_tiles = ceil_div(a.M, TE);
     const long long resident = (long long)g_cus * (lds_bytes <= 80 * 1024 ? 2 : 1);   // persistent workgroups
     const unsigned grid = (unsigned)(n_tiles < resident ? n_tiles : resident);
-    auto kern = k_mlp_f32_split3<NW, NTH, NTO, NL>;
+    auto kern = k_mlp_f32_split3<NW, NTH, NTO, NL, ACT_H, ACT_O>;
     HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     kern<<<grid, NTHR, lds_bytes, s>>>(a);
     HGNN_CHECK_HIP(hipGetLastError());
     return HGNN_OK;
+}
+
+// activation codes as template parameters for the combinations the models use (hidden GELU + Tanh / GELU output:
+// edge / node / supernode / superedge networks and encoders; Tanh + Tanh: the hidden layers of the score heads);
+// anything else runs the runtime-switch instantiation
+template <int NW, int NTH, int NTO, int NL>
+static int launch(const Args& a, hipStream_t s) {
+    bool hidden_gelu = true, hidden_tanh = true;
+    for (int l = 0; l + 1 < NL; ++l) {
+        hidden_gelu = hidden_gelu && a.act[l] == HGNN_ACT_GELU;
+        hidden_tanh = hidden_tanh && a.act[l] == HGNN_ACT_TANH;
+    }
+    const int out = a.act[NL - 1];
+    if (hidden_gelu && out == HGNN_ACT_TANH) return launch_act<NW, NTH, NTO, NL, HGNN_ACT_GELU, HGNN_ACT_TANH>(a, s);
+    if (hidden_gelu && out == HGNN_ACT_GELU) return launch_act<NW, NTH, NTO, NL, HGNN_ACT_GELU, HGNN_ACT_GELU>(a, s);
+    if (hidden_tanh && out == HGNN_ACT_TANH) return launch_act<NW, NTH, NTO, NL, HGNN_ACT_TANH, HGNN_ACT_TANH>(a, s);
+    return launch_act<NW, NTH, NTO, NL, -1, -1>(a, s);
 }
 
 }  // namespace f3
