@@ -14,6 +14,8 @@ cover take the library path.
 """
 from __future__ import annotations
 
+import contextlib
+import contextvars
 import ctypes
 import os
 import weakref
@@ -34,6 +36,39 @@ _enabled = True
 # without checkpointing) and is the default when autograd records.
 _train_enabled = True
 stats = {"fused_calls": 0, "fused_train_calls": 0}
+
+# Dispatch switches.  The module-level ``_name`` variables below are the PROCESS DEFAULTS (what the ``set_*`` functions
+# and the HGNN_* environment variables change).  ``options(...)`` overrides any of them for the current context only --
+# a ``contextvars`` context, i.e. per thread / per asyncio task -- so two models served from two threads can run
+# different arithmetic (``with fused.options(fp32_split3=False): model(x, g)``) without touching shared state.
+_ctx_options = contextvars.ContextVar("hgnn_fused_options", default=None)
+_ctx_training_forward = contextvars.ContextVar("hgnn_fused_training_forward", default=0)
+_OPTION_NAMES = ("enabled", "train_enabled", "preproject", "preproject_bf16", "fp32_split3", "fp32_split3_train",
+                 "bf16_split", "train_bf16_enabled", "wgrad_hip", "bwd_fused")
+
+
+def _opt(name: str):
+    o = _ctx_options.get()
+    if o is not None and name in o:
+        return o[name]
+    return globals()["_" + name]
+
+
+@contextlib.contextmanager
+def options(**overrides):
+    """Context-local dispatch overrides: ``enabled``, ``train_enabled``, ``preproject``, ``preproject_bf16``,
+    ``fp32_split3``, ``fp32_split3_train``, ``bf16_split``, ``train_bf16_enabled``, ``wgrad_hip``, ``bwd_fused``.
+    Nested contexts stack; nothing outside the ``with`` block (or in another thread) sees the change."""
+    bad = set(overrides) - set(_OPTION_NAMES)
+    if bad:
+        raise TypeError(f"fused.options: unknown option(s) {sorted(bad)}; known: {_OPTION_NAMES}")
+    merged = dict(_ctx_options.get() or {})
+    merged.update(overrides)
+    token = _ctx_options.set(merged)
+    try:
+        yield
+    finally:
+        _ctx_options.reset(token)
 
 
 def set_enabled(flag: bool, train: bool = None):
@@ -91,7 +126,7 @@ def _projected_segments(segments, M):
     linearly, W_s table[idx[e]] = (table W_s^T)[idx[e]], so a table with few rows (nodes: N = M / 16.7) is
     projected once by an N-row GEMM and only gathered inside the kernel -- the edge network's first layer
     keeps K = L of its 3L input columns.  At least one segment must stay in the kernel's K loop."""
-    if not _preproject or len(segments) < 2 or any(int(t.shape[1]) % 16 for t, _ in segments):
+    if not _opt("preproject") or len(segments) < 2 or any(int(t.shape[1]) % 16 for t, _ in segments):
         return []
     cand = [i for i, (t, idx) in enumerate(segments) if idx is not None and 4 * int(t.shape[0]) <= M]
     cand = cand[:2]
@@ -363,29 +398,28 @@ def set_fp32_split3(flag: bool) -> None:
     _fp32_split3 = bool(flag)
 
 
-_training_forward_depth = 0
-
-
 class training_forward:
     """context: the enclosed no-grad evaluation belongs to a TRAINING step (the first pass of a reentrant
     ``torch.utils.checkpoint`` segment, gnn_utils._maybe_checkpoint).  The split-bf16 evaluation of the fp32 MLPs is an
     INFERENCE default; inside this context a no-grad forward uses exactly what the recompute under autograd will use
     (the exact fp32 kernels, or split-bf16 everywhere with set_fp32_split3_training(True)): forward values and the
-    point the gradients are taken at agree bitwise, as with the reference's own recompute."""
+    point the gradients are taken at agree bitwise, as with the reference's own recompute.  Context-local
+    (``contextvars``): a training step in one thread does not change what an inference call in another thread runs."""
 
     def __enter__(self):
-        global _training_forward_depth
-        _training_forward_depth += 1
+        self._token = _ctx_training_forward.set(_ctx_training_forward.get() + 1)
 
     def __exit__(self, *exc):
-        global _training_forward_depth
-        _training_forward_depth -= 1
+        _ctx_training_forward.reset(self._token)
         return False
 
 
 def _split3_on(net) -> bool:
-    if _training_forward_depth > 0 and not _fp32_split3_train:
+    if _ctx_training_forward.get() > 0 and not _opt("fp32_split3_train"):
         return False
+    o = _ctx_options.get()
+    if o is not None and "fp32_split3" in o:        # an explicit context override outranks the per-module mark
+        return bool(o["fp32_split3"])
     flag = getattr(net, "_hgnn_split3", None)      # per-module override (hparams["fp32_gemm"])
     return _fp32_split3 if flag is None else bool(flag)
 
@@ -418,7 +452,7 @@ def _split3_linear(x: torch.Tensor, weight, cols, net) -> Optional[torch.Tensor]
     off / the shape has no instantiation (the caller then uses the library's fp32 GEMM)"""
     K = int(x.shape[1])
     N = int(weight.shape[1]) if cols is None else cols[1] - cols[0]
-    if not (_fp32_split3_train and _split3_on(net)) or x.dtype != torch.float32 or not x.is_cuda or K % 128 \
+    if not (_opt("fp32_split3_train") and _split3_on(net)) or x.dtype != torch.float32 or not x.is_cuda or K % 128 \
             or N not in (256, 512) \
             or int(x.shape[0]) == 0:
         return None
@@ -455,7 +489,7 @@ def _split3_project(table: torch.Tensor, weight, cols) -> Optional[torch.Tensor]
 def _split3_applies(net, segments, training: bool = False) -> bool:
     """the opt-in split-bf16 path is switched on for this network and hgnn_mlp_forward_f32_split3 has its shape
     (``training``: the call comes from the differentiable forward, which dumps the pre-LayerNorm rows)"""
-    if not _split3_on(net) or (training and not _fp32_split3_train):
+    if not _split3_on(net) or (training and not _opt("fp32_split3_train")):
         return False
     if not training and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
         return False
@@ -504,7 +538,7 @@ def set_bf16_split(flag: bool) -> None:
 
 def _wants_split(net, segments) -> bool:
     layers = _parse(net)
-    if not _bf16_split or layers is None or len(layers) not in (1, 2, 3):
+    if not _opt("bf16_split") or layers is None or len(layers) not in (1, 2, 3):
         return False
     if any(int(t.shape[1]) % 128 for t, _ in segments):
         return False
@@ -538,7 +572,7 @@ def _descriptor_bf16(net, segments, skip, split=False, dry=False):
     lin0 = layers[0][0]
     if lin0.in_features != sum(int(t.shape[1]) for t, _ in segments) or not lin0.weight.is_cuda:
         return None
-    want_pre = _preproject_bf16
+    want_pre = _opt("preproject_bf16")
     if want_pre is None:
         widths = [lin.out_features for lin, _, _ in layers]
         want_pre = len(layers) > 1 and lin0.out_features >= 512
@@ -663,10 +697,10 @@ def _is_bf16(segments) -> bool:
     return all(t.dtype == torch.bfloat16 for t, _ in segments)
 
 
-def supported(net, segments, skip, allow_chain: bool = True) -> bool:
+def supported(net, segments, skip, allow_chain: bool = True) -> bool:  # noqa: C901
     """``allow_chain``: accept fp32 MLPs that run as one launch per layer (latent 512); a caller that has a cheaper
     alternative for them (bf16 tail of the encoders in bf16 mode) passes False"""
-    if not _enabled:
+    if not _opt("enabled"):
         return False
     if _is_bf16(segments):
         if torch.is_grad_enabled():
@@ -826,7 +860,7 @@ def _atb(A: torch.Tensor, B: torch.Tensor, net=None) -> torch.Tensor:
     8 GFLOP of n = 120k, ~110 TFLOP/s at n = 2M); a batched product over row blocks plus one sum fills the
     chip (fixed summation order: deterministic).  EC-IN training step 368 -> 306 ms."""
     n = int(A.shape[0])
-    if net is not None and _fp32_split3_train and _split3_on(net) and n >= 4096 and A.dtype == torch.float32 and B.dtype == torch.float32 \
+    if net is not None and _opt("fp32_split3_train") and _split3_on(net) and n >= 4096 and A.dtype == torch.float32 and B.dtype == torch.float32 \
             and A.is_cuda and int(A.shape[1]) % 8 == 0 and int(B.shape[1]) % 8 == 0:
         from .ops import wgrad_f32_split3
         stats["split3_wgrad_calls"] = stats.get("split3_wgrad_calls", 0) + 1
@@ -1012,10 +1046,10 @@ class _FusedMLPTrain(torch.autograd.Function):
 def supported_train(net, segments, skip) -> bool:
     """differentiable fused path: cell networks (LayerNorm on every layer, 16-aligned segments); bf16 rows:
     the feature-split kernel's shapes at latent 128 / 256 (``_FusedMLPTrainBf16``)"""
-    if not _train_enabled or not torch.is_grad_enabled():
+    if not _opt("train_enabled") or not torch.is_grad_enabled():
         return False
     if _is_bf16(segments):
-        if not _train_bf16_enabled or not _wants_split(net, segments):
+        if not _opt("train_bf16_enabled") or not _wants_split(net, segments):
             return False
         layers = _parse(net)
         if any(lin.out_features not in (64, 128, 256, 512, 1024) for lin, _, _ in layers):
@@ -1084,7 +1118,7 @@ def set_train_bf16(flag: bool, wgrad_hip: bool = True) -> None:
 
 def _wgrad(dz: torch.Tensor, rows: torch.Tensor, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 dz^T rows of bf16 operands (+ optionally dz's column sums = the bias gradient, from the same pass)"""
-    if _wgrad_hip:
+    if _opt("wgrad_hip"):
         from .ops import wgrad_bf16
         return wgrad_bf16(dz, rows, colsum=colsum)
     if colsum is not None:
@@ -1219,8 +1253,8 @@ class _FusedMLPTrainBf16(torch.autograd.Function):
         for l in range(n - 1, 0, -1):
             K, N = int(W[l].shape[0]), int(W[l].shape[1])
             need_bias = grads_params[4 * l + 1] is None
-            colsum = torch.empty(K, dtype=torch.float32, device=dz.device) if need_bias and _wgrad_hip else None
-            if _bwd_fused and _bwd_layer_supported(K, N):
+            colsum = torch.empty(K, dtype=torch.float32, device=dz.device) if need_bias and _opt("wgrad_hip") else None
+            if _opt("bwd_fused") and _bwd_layer_supported(K, N):
                 # hand-written data gradient fused with the LayerNorm / activation backward of the layer below
                 dz_prev, a_prev, dlw, dlb = _bwd_layer(dz, W[l], zs[l - 1], lnw[l - 1], lnb[l - 1], ctx.acts[l - 1],
                                                        ctx.eps, want_a=True)
@@ -1261,7 +1295,7 @@ class _FusedMLPTrainBf16(torch.autograd.Function):
                 del S
             else:
                 colsum = None
-                if need_bias and _wgrad_hip:
+                if need_bias and _opt("wgrad_hip"):
                     colsum = torch.empty(H0, dtype=torch.float32, device=dz.device)
                 dW[:, col:col + w_s] = _wgrad(dz, tab, colsum)
                 if colsum is not None:
@@ -1269,7 +1303,7 @@ class _FusedMLPTrainBf16(torch.autograd.Function):
                     need_bias = False
                 if ctx.needs_input_grad[3 + s_i]:
                     folded = ctx.skip_seg == s_i          # edges + MLP(..., edges): both gradients in one epilogue
-                    if _bwd_fused and _bwd_layer_supported(H0, w_s):
+                    if _opt("bwd_fused") and _bwd_layer_supported(H0, w_s):
                         grads_tables[s_i] = _bwd_layer(dz, W[0][:, col:col + w_s], None, None, None, 0, ctx.eps,
                                                        skip=g if folded else None)[0]
                     elif folded:

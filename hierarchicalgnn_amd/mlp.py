@@ -37,7 +37,7 @@ def concat_mlp(net: nn.Sequential, segments: Sequence[Segment], skip: Optional[t
         if not bf16_tail and fused.supported(net, segments, skip):
             return fused.fused_concat_mlp(net, segments, skip, out=out)
         return out.copy_(concat_mlp(net, segments, skip, bf16_tail))
-    if bf16_tail and skip is None and len(net) > 3 and not torch.is_grad_enabled() and fused._enabled:
+    if bf16_tail and skip is None and len(net) > 3 and not torch.is_grad_enabled() and fused._opt("enabled"):
         # bf16 latent mode, encoders: hybrid chain -- the first Linear (hit coordinates: must not be rounded to 8
         # bits) as ONE fp32 fused layer, the wide tail on the bf16 feature-split kernel (edge encoder at latent 256,
         # 2M rows: 3.0 instead of 5.6 ms for the all-fp32 fused kernel)

@@ -345,3 +345,38 @@ def test_checkpointed_training_forward_is_bitwise_deterministic_and_exact_by_def
         assert not torch.equal(se, xe) and float((se - xe).abs().max()) < 1e-4
     finally:
         fused.set_fp32_split3(old)
+
+
+def test_dispatch_options_are_context_local():
+    """``fused.options(...)`` overrides a dispatch switch for the current context (thread / task) only: the same MLP
+    runs the exact fp32 kernel inside the block and the split-bf16 default outside it; another thread started inside
+    the block still sees the process default"""
+    import threading
+    from hierarchicalgnn_amd import fused, make_mlp
+    old = fused._fp32_split3
+    fused.set_fp32_split3(True)
+    try:
+        torch.manual_seed(9)
+        L, M = 128, 300
+        net = make_mlp(L, 2 * L, L, 2, layer_norm=True, output_activation="Tanh", hidden_activation="GELU").cuda()
+        x = torch.randn(M, L, device="cuda")
+        with torch.no_grad():
+            n0 = fused.stats.get("split3_calls", 0)
+            a = fused.fused_concat_mlp(net, [(x, None)], None)
+            assert fused.stats.get("split3_calls", 0) == n0 + 1
+            seen = []
+            with fused.options(fp32_split3=False):
+                b = fused.fused_concat_mlp(net, [(x, None)], None)
+                assert fused.stats.get("split3_calls", 0) == n0 + 1          # the exact kernel ran
+                t = threading.Thread(target=lambda: seen.append(fused._opt("fp32_split3")))
+                t.start()
+                t.join()
+                with pytest.raises(TypeError):
+                    with fused.options(no_such_switch=1):
+                        pass
+            assert seen == [True]                                            # other contexts keep the default
+            c = fused.fused_concat_mlp(net, [(x, None)], None)
+            assert fused.stats.get("split3_calls", 0) == n0 + 2
+        assert torch.equal(a, c) and not torch.equal(a, b) and float((a - b).abs().max()) < 1e-4
+    finally:
+        fused.set_fp32_split3(old)
