@@ -58,7 +58,11 @@ def _opt(name: str):
 def options(**overrides):
     """Context-local dispatch overrides: ``enabled``, ``train_enabled``, ``preproject``, ``preproject_bf16``,
     ``fp32_split3``, ``fp32_split3_train``, ``bf16_split``, ``train_bf16_enabled``, ``wgrad_hip``, ``bwd_fused``.
-    Nested contexts stack; nothing outside the ``with`` block (or in another thread) sees the change."""
+    Nested contexts stack; nothing outside the ``with`` block (or in another thread) sees the change.
+    NOTE for training: autograd runs the backward (and the recompute of reentrant checkpoints) on its own worker
+    thread, which does NOT inherit this context -- switches that must hold during ``backward()`` (``fp32_split3_train``,
+    ``train_enabled``, ``train_bf16_enabled``, ``wgrad_hip``, ``bwd_fused``) are to be set as process defaults
+    (``set_*`` functions / HGNN_* environment variables); ``options`` is for inference-side choices."""
     bad = set(overrides) - set(_OPTION_NAMES)
     if bad:
         raise TypeError(f"fused.options: unknown option(s) {sorted(bad)}; known: {_OPTION_NAMES}")

@@ -220,3 +220,71 @@ def test_distributed_bc_forward_training_mode_synchronised_batch_norm_on_rccl_wo
     ga = {k: p.grad for k, p in model.named_parameters()}
     gb = {k: p.grad for k, p in twin.named_parameters()}
     assert {k for k, g in ga.items() if g is not None} == {k for k, g in gb.items() if g is not None}
+
+
+def test_config5_full_pileup_shard_of_eight_equals_the_unpartitioned_cell():
+    """BASELINE config 5's event (480k hits, 4M edges -> 8M directed rows) cut into EIGHT phi-wedges on the device; the
+    HIP cell runs rank 3's shard with the overlapped interior / boundary schedule (its halo replayed from the
+    unpartitioned result, as the peers would send it) and reproduces the unpartitioned cell on its hits and edges"""
+    import hierarchicalgnn_amd as H
+    from hierarchicalgnn_amd import partition, synth
+    torch.manual_seed(2)
+    L = 128
+    hp = dict(latent=L, hidden=2 * L, nb_edge_layer=2, nb_node_layer=3, layernorm=True, hidden_activation="GELU")
+    cell = H.InteractionGNNCell(hp).cuda().eval()
+    x, ei = synth.trackml_event(480_000, 4_000_000, seed=1234)
+    x, ei = x.cuda(), ei.cuda()
+    graph = torch.cat([ei, ei.flip(0)], dim=1)
+    gen = torch.Generator("cuda").manual_seed(4)
+    nodes = torch.randn(480_000, L, device="cuda", generator=gen)
+    edges = torch.randn(graph.shape[1], L, device="cuda", generator=gen)
+    with torch.no_grad():
+        ref_n, ref_e = cell(nodes, edges, graph)
+        shard = partition.partition_event(x, ei, 8, 3)
+        assert 0.9 < shard.local_graph.shape[1] / (graph.shape[1] / 8) < 1.1          # balanced on rows
+        assert 0 < shard.n_halo < 0.05 * shard.n_owned                                 # phi-wedges: a thin halo
+        halo = _ReplayHalo(shard, ref_n)
+        out_n, out_e = partition.distributed_cell_forward(cell, halo, nodes[shard.owned_global],
+                                                          edges[shard.edge_global], shard.local_graph)
+    torch.cuda.synchronize()
+    assert float((out_n - ref_n[shard.owned_global]).abs().max()) <= 1e-4 * float(ref_n.abs().max())
+    assert float((out_e - ref_e[shard.edge_global]).abs().max()) <= 1e-4 * float(ref_e.abs().max())
+
+
+def test_config5_partitioned_bc_forward_at_full_pileup_size_on_rccl_world1(rccl_world1):
+    """the partitioned BC-HGNN-GMM forward (config 5's model path: all-gathered embeddings, replicated hierarchy, all-reduced
+    pooling sums, halo exchange + overlapped edge updates, RCCL collectives) on the FULL-PILEUP event with a real RCCL
+    communicator of one rank: scores equal the plain model's on the same bipartite edges.  (The hierarchy decision is a
+    fixed phi-z binning on both sides: random-init embeddings make the GMM cut degenerate.)"""
+    from hierarchicalgnn_amd import partition, synth
+    from hierarchicalgnn_amd.models import BC_MessagePassing
+    hp = dict(spatial_channels=3, latent=64, hidden=128, emb_dim=8, n_interaction_graph_iters=2,
+              n_hierarchical_graph_iters=2, nb_node_layer=3, nb_edge_layer=2, output_layers=3,
+              hidden_output_activation="Tanh", hidden_activation="GELU", layernorm=True, share_weight=False,
+              bipartitegraph_sparsity=5, supergraph_sparsity=10, min_cluster_size=3, cluster_granularity=5)
+    torch.manual_seed(3)
+    model = BC_MessagePassing(hp).cuda().eval()
+    model.hgnn_block.super_graph_construction.knn_radius.fill_(2.0)
+    model.hgnn_block.bipartite_graph_construction.knn_radius.fill_(2.0)
+    x, ei = synth.trackml_event(480_000, 4_000_000, seed=1234)
+    xd, eid = x.cuda(), ei.cuda()
+    cl = ((xd[:, 1] + 1) * 50).long().clamp(0, 99) * 100 + ((xd[:, 2] + 1) * 50).long().clamp(0, 99)
+    _, clusters = torch.unique(cl, return_inverse=True)
+    n_cl = int(clusters.max()) + 1
+    with torch.no_grad():
+        directed, emb, nodes, edges, _ = model.embed(xd, eid)
+        means, bg, bw, sg, sw, _ = model.hgnn_block.hierarchy_from_clusters(emb, clusters, n_cl)
+        n_out, sn_out, _, _ = model.hgnn_block(nodes, edges, directed, means, bg, bw, sg, sw)
+        s_ref = model.score(n_out, sn_out, bg)
+        shard = partition.partition_event(xd, eid, 1, 0)
+        halo = partition.HaloExchange(shard, "cuda", mode="all_to_all")
+        owned = partition.all_owned_lists(xd, eid, 1)
+        pieces = partition.bc_pieces_from_model(model)
+        pieces["cluster"] = lambda e, g: (clusters, n_cl)
+        bg2, s2, emb2 = partition.distributed_bc_forward(pieces, shard, halo, xd[shard.owned_global], owned,
+                                                         torch.cat([eid, eid.flip(0)], dim=1))
+    key = lambda g: g[0] * 100000 + g[1]
+    o_ref, o = torch.argsort(key(bg)), torch.argsort(key(bg2))
+    assert torch.equal(key(bg)[o_ref], key(bg2)[o])
+    assert s2.shape[0] == 480_000 * 5 and float((s2[o] - s_ref[o_ref]).abs().max()) <= 1e-4
+    assert torch.allclose(emb2, emb[shard.owned_global], rtol=1e-4, atol=1e-5)
