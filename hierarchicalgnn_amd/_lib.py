@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("HGNN_LIB") or os.path.join(_HERE, "csrc", "libhgnn_hi
 
 HGNN_OK = 0
 CNT_WORK, CNT_SPLIT, CNT_PARTIAL, CNT_ERR, CNT_VALID, CNT_UNSORTED = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 22
+ABI_VERSION = 23
 MLP_BWD_BLOCKS = 512   # HGNN_MLP_BWD_BLOCKS
 GMM_STATE, GMM_BLOCKS = 16, 1024   # HGNN_GMM_STATE, HGNN_GMM_BLOCKS
 LN_ACT_BLOCKS = 1024   # HGNN_LN_ACT_BLOCKS
@@ -107,6 +107,8 @@ _SIGNATURES = {
     "hgnn_mlp_supported_f32_split3": (c_int, [POINTER(HgnnMlpDesc)]),
     "hgnn_mlp_forward_f32_split3": (c_int, [POINTER(HgnnMlpDesc), c_void_p, c_void_p]),
     "hgnn_linear_f32_split3": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "hgnn_project_f32_split3": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                        c_void_p]),
     "hgnn_ln_act_forward_f32": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_float,
                                         c_void_p, c_void_p]),
     "hgnn_ln_act_backward_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32,

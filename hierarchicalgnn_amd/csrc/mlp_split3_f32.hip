@@ -476,12 +476,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
 // out[M, N] = x[M, K] . W^T (+ skip): ONE plain fp32 Linear without bias / LayerNorm on the same split-bf16 loop -- the
 // M-row data-gradient GEMMs of the fp32 training backward (dz . W of Modules/utils.py:169-196's Linear under autograd;
 // the library's fp32 GEMM runs them at ~130 TFLOP/s).  N = NT NW 16; K a multiple of 128; W as in the MLP kernel.
-template <int NW, int NT>
+// blockIdx.y selects one of up to two (weight stream, output) pairs over the SAME input rows: the two pre-projections of
+// an edge update (P_s = nodes . W_s^T for the source and the destination segment) run as one launch (hgnn_project_f32_split3)
+template <int NW, int NT, bool FOUR>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_linear_f32_split3(const float* __restrict__ x, int K,
-                                                                               const unsigned short* __restrict__ W,
+                                                                               const unsigned short* __restrict__ W0,
+                                                                               const unsigned short* __restrict__ W1,
                                                                                const float* __restrict__ skip,
-                                                                               float* __restrict__ out, long long M) {
+                                                                               float* __restrict__ out0,
+                                                                               float* __restrict__ out1, long long M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned short* __restrict__ W = blockIdx.y == 0 ? W0 : W1;
+    float* __restrict__ out = blockIdx.y == 0 ? out0 : out1;
     constexpr int NTHR = NW * 64;
     constexpr int N = NT * NW * 16;
     constexpr int LPR = PK * 4 / 16;
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_linear_f32_split3(
         const bool more = p + 1 < np;
         if (more) load_panel();
         const char* bh = blane + (2 * (p & 1)) * PANEL;
-        gemm3s<NT, PRS, NW, true>(acc, wp, 2 * p * CPP, vtotal, bh, bh + PANEL, CPP);
+        gemm3s<NT, PRS, NW, FOUR>(acc, wp, 2 * p * CPP, vtotal, bh, bh + PANEL, CPP);
         if (more) store_panel((p + 1) & 1);
         __syncthreads();
     }
@@ -552,13 +558,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_linear_f32_split3(
     }
 }
 
-template <int NW, int NT>
-static int launch_linear(const float* x, int K, const unsigned short* W, const float* skip, float* out, long long M,
-                         hipStream_t s) {
+template <int NW, int NT, bool FOUR>
+static int launch_linear(const float* x, int K, const unsigned short* W0, const unsigned short* W1, const float* skip,
+                         float* out0, float* out1, long long M, hipStream_t s) {
     const size_t lds_bytes = (size_t)4 * PANEL;
-    auto kern = k_linear_f32_split3<NW, NT>;
+    auto kern = k_linear_f32_split3<NW, NT, FOUR>;
     HGNN_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    kern<<<(unsigned)ceil_div(M, TE), NW * 64, lds_bytes, s>>>(x, K, W, skip, out, M);
+    kern<<<dim3((unsigned)ceil_div(M, TE), W1 != nullptr ? 2 : 1), NW * 64, lds_bytes, s>>>(x, K, W0, W1, skip, out0, out1, M);
     HGNN_CHECK_HIP(hipGetLastError());
     return HGNN_OK;
 }
@@ -702,6 +708,24 @@ extern "C" int hgnn_linear_f32_split3(const float* x, int64_t M, int32_t K, cons
     HGNN_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w_split % 16 == 0 && (uintptr_t)out % 16 == 0 &&
                      (uintptr_t)skip % 16 == 0,
                  "hgnn_linear_f32_split3: pointers must be 16-byte aligned");
-    if (N == 512) return f3::launch_linear<8, 4>(x, K, (const unsigned short*)w_split, skip, out, M, stream);
-    return f3::launch_linear<4, 4>(x, K, (const unsigned short*)w_split, skip, out, M, stream);
+    if (N == 512) return f3::launch_linear<8, 4, true>(x, K, (const unsigned short*)w_split, nullptr, skip, out, nullptr, M, stream);
+    return f3::launch_linear<4, 4, true>(x, K, (const unsigned short*)w_split, nullptr, skip, out, nullptr, M, stream);
+}
+
+extern "C" int hgnn_project_f32_split3(const float* x, int64_t M, int32_t K, const void* w_split0, const void* w_split1,
+                                       int32_t N, float* out0, float* out1, hgnn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    HGNN_REQUIRE(M >= 0 && M <= 0x7fffffffLL && K > 0 && K % 128 == 0 && (N == 256 || N == 512),
+                 "hgnn_project_f32_split3: M = %lld, K = %d (multiple of 128), N = %d (256 or 512)", (long long)M, K, N);
+    if (M == 0) return HGNN_OK;
+    HGNN_REQUIRE(x != nullptr && w_split0 != nullptr && out0 != nullptr && (w_split1 == nullptr) == (out1 == nullptr),
+                 "hgnn_project_f32_split3: NULL argument (w_split1 / out1 are given together or not at all)");
+    HGNN_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w_split0 % 16 == 0 && (uintptr_t)w_split1 % 16 == 0 &&
+                     (uintptr_t)out0 % 16 == 0 && (uintptr_t)out1 % 16 == 0,
+                 "hgnn_project_f32_split3: pointers must be 16-byte aligned");
+    if (N == 512)
+        return f3::launch_linear<8, 4, false>(x, K, (const unsigned short*)w_split0, (const unsigned short*)w_split1, nullptr,
+                                              out0, out1, M, stream);
+    return f3::launch_linear<4, 4, false>(x, K, (const unsigned short*)w_split0, (const unsigned short*)w_split1, nullptr, out0,
+                                          out1, M, stream);
 }

@@ -172,6 +172,22 @@ def _descriptor(net, segments, skip, dry=False, split_proj=False):
     if lin0.in_features != K_full:
         return None
     proj = _projected_segments(segments, M) if layers[0][1] is not None else []
+    split_P = {}
+    if split_proj and proj and not dry:
+        # the pre-projections in the consuming kernel's own arithmetic; both segments of one table (nodes[graph[0]],
+        # nodes[graph[1]]) in one launch
+        cols, c0 = {}, 0
+        for i, (t, _) in enumerate(segments):
+            cols[i] = (c0, c0 + int(t.shape[1]))
+            c0 += int(t.shape[1])
+        t0 = segments[proj[0]][0]
+        same = len(proj) == 2 and segments[proj[1]][0].data_ptr() == t0.data_ptr() \
+            and segments[proj[1]][0].shape == t0.shape and t0.is_contiguous() and segments[proj[1]][0].is_contiguous()
+        groups = [proj] if same else [[i] for i in proj]
+        for grp in groups:
+            res = _split3_project(segments[grp[0]][0].detach(), lin0.weight, [cols[i] for i in grp])
+            if res is not None:
+                split_P.update(dict(zip(grp, res)))
     col = 0
     kept_cols = []
     n_kept = n_pre = 0
@@ -187,7 +203,7 @@ def _descriptor(net, segments, skip, dry=False, split_proj=False):
             if dry:
                 P = t
             else:
-                P = _split3_project(t.detach(), lin0.weight, (col, col + w)) if split_proj else None
+                P = split_P.get(i)
                 if P is None:
                     with torch.autocast("cuda", enabled=False):   # the kernel reads P as fp32
                         P = torch.matmul(t.detach(), lin0.weight.detach()[:, col:col + w].t())   # [rows, H]
@@ -472,22 +488,26 @@ def _split3_linear(x: torch.Tensor, weight, cols, net) -> Optional[torch.Tensor]
     return out
 
 
-def _split3_project(table: torch.Tensor, weight, cols) -> Optional[torch.Tensor]:
-    """table [R, w] . W[:, cols]^T -> [R, H]: the pre-projection of a gathered segment (``_projected_segments``) in
-    split-bf16 arithmetic (four products), or None when the shape has no instantiation"""
+def _split3_project(table: torch.Tensor, weight, cols_list):
+    """[table [R, w] . W[:, cols]^T -> [R, H] for cols in cols_list] (one or two column blocks of the first Linear over
+    the SAME table): the pre-projections of the gathered segments (``_projected_segments``) in the split-bf16 arithmetic
+    of the kernel that consumes them (three products), ONE launch (hgnn_project_f32_split3); None when the shape has no
+    instantiation"""
     R, K = int(table.shape[0]), int(table.shape[1])
     N = int(weight.shape[0])
-    if R == 0 or K % 128 or N not in (256, 512) or table.dtype != torch.float32 or not table.is_cuda:
+    if R == 0 or K % 128 or N not in (256, 512) or table.dtype != torch.float32 or not table.is_cuda \
+            or not 1 <= len(cols_list) <= 2:
         return None
     # the kernel wants the weight of the Linear that maps K -> N: W[:, cols]  [N, K]
-    Wv = _split3_weight(weight, (tuple(cols),), False)
+    Wv = [_split3_weight(weight, (tuple(c),), False) for c in cols_list]
     tc = table if table.is_contiguous() else table.contiguous()
-    out = torch.empty((R, N), dtype=torch.float32, device=table.device)
+    outs = [torch.empty((R, N), dtype=torch.float32, device=table.device) for _ in cols_list]
     with torch.cuda.device(table.device):
-        _lib.check(_lib.load().hgnn_linear_f32_split3(_lib.ptr(tc), R, K, _lib.ptr(Wv), N, None, _lib.ptr(out),
-                                                      _lib.current_stream(table.device)), "hgnn_linear_f32_split3")
+        _lib.check(_lib.load().hgnn_project_f32_split3(
+            _lib.ptr(tc), R, K, _lib.ptr(Wv[0]), _lib.ptr(Wv[1]) if len(Wv) > 1 else None, N, _lib.ptr(outs[0]),
+            _lib.ptr(outs[1]) if len(outs) > 1 else None, _lib.current_stream(table.device)), "hgnn_project_f32_split3")
     stats["split3_project_calls"] = stats.get("split3_project_calls", 0) + 1
-    return out
+    return outs
 
 
 def _split3_applies(net, segments, training: bool = False) -> bool:

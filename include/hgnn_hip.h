@@ -50,7 +50,7 @@ extern "C" {
 #define HGNN_ERR_WORKSPACE 3
 #define HGNN_ERR_UNSUPPORTED 4
 
-#define HGNN_ABI_VERSION 22
+#define HGNN_ABI_VERSION 23
 
 typedef void* hgnn_stream_t; /* hipStream_t */
 
@@ -339,6 +339,13 @@ int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, hgnn_stream_
  * GEMMs of the fp32 training backward.  K a multiple of 128, N in {256, 512}; skip [M, N] or NULL. */
 int hgnn_linear_f32_split3(const float* x, int64_t M, int32_t K, const void* w_split, int32_t N,
                            const float* skip, float* out, hgnn_stream_t stream);
+
+/* The pre-projections of an edge update in ONE launch: out_s[M, N] = x[M, K] . W_s^T for s = 0 (and 1, when w_split1 /
+ * out1 are given) over the same input rows (x = the node table, W_s = the first Linear's column block of gathered
+ * segment s; hgnn_mlp_desc.pre_table).  Same split-bf16 arithmetic as hgnn_mlp_forward_f32_split3 itself (three
+ * products), same weight stream layout as hgnn_linear_f32_split3.  K a multiple of 128, N in {256, 512}. */
+int hgnn_project_f32_split3(const float* x, int64_t M, int32_t K, const void* w_split0, const void* w_split1,
+                            int32_t N, float* out0, float* out1, hgnn_stream_t stream);
 
 /* LayerNorm + activation of one make_mlp layer (Modules/utils.py:169-196: Linear -> LayerNorm ->
  * act) over rows z[M, W] (the Linear's output, as dumped by hgnn_mlp_forward_f32's save_pre), one
