@@ -45,7 +45,24 @@ struct Args {
     const int32_t* pre_index[2];
     int n_pre;
     float* save_pre[3];   // optional fp32 [M, width_l] dumps of each layer's pre-LayerNorm output (training forward)
+#ifdef HGNN_SPLIT3_STAMPS
+    unsigned long long* stamps;   // DIAGNOSTIC build (tools/split3_stamps.hip): [tiles][waves][9] shader-clock stamps
+    long long stamp_tiles;
+#endif
 };
+
+// phase boundaries of a tile, stamped by lane 0 of every wave in the diagnostic build only (no stamp executes in the
+// product build): 0 tile start | 1 projected rows added | 2 first panel stored | 3 layer-1 GEMM done | 4 LayerNorm + GELU done
+// | 5 hidden planes written | 6 output GEMM done | 7 output LayerNorm + tanh done | 8 rows stored
+#ifdef HGNN_SPLIT3_STAMPS
+#define HGNN_STAMP(k)                                                                                              \
+    do {                                                                                                           \
+        if (a.stamps != nullptr && tile < a.stamp_tiles && (threadIdx.x & 63) == 0)                                \
+            a.stamps[((size_t)tile * NW + (threadIdx.x >> 6)) * 9 + (k)] = __builtin_amdgcn_s_memtime();             \
+    } while (0)
+#else
+#define HGNN_STAMP(k) do { } while (0)
+#endif
 
 constexpr int NJ = 4;
 constexpr int TE = 64;
@@ -323,6 +340,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
         const bool has_next = tile + gridDim.x < n_tiles;
         const long long e0 = tile * TE;
         refresh();
+        HGNN_STAMP(0);
         const float* px[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i)
@@ -389,9 +407,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
             }
             __syncthreads();
         }
+        HGNN_STAMP(1);
         {
             store_panel(0);
             __syncthreads();
+            HGNN_STAMP(2);
             const char* blane = smem + ei * PRS + (g << 4);
             for (int p = 0; p < np; ++p) {
                 const bool more = p + 1 < np;
@@ -402,12 +422,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
                 __syncthreads();
             }
         }
+        HGNN_STAMP(3);
         dump_pre<NTH, H>(acc1, a.save_pre[0], a.M, e0, wave, ei, g);
         layernorm_act<NTH, NW, ACT_H>(acc1, a.lnw[0] + wave * NTH * 16 + 4 * g, a.lnb[0] + wave * NTH * 16 + 4 * g, a.act[0],
                                       a.eps, red, wave, ei, g);
         // (the barrier inside layernorm_act also means: every wave is done reading the panels)
+        HGNN_STAMP(4);
         write_hidden2<NTH, HRS, PLB>(acc1, smem, wave, ei, g);
         __syncthreads();
+        HGNN_STAMP(5);
         const char* hlane = smem + ei * HRS + (g << 4);
         if constexpr (NL == 3) {
             // ---------------- middle layer (same width), hidden planes rewritten in place
@@ -434,6 +457,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
             const u16x8* wpo = (const u16x8*)a.W[LO] + (size_t)(wave * NTO) * 64 + lane;
             gemm3s<NTO, HRS, NW>(acc2, wpo, 0, 2 * NC, hlane, hlane + PLB, NC);
         }
+        HGNN_STAMP(6);
 #pragma unroll
         for (int k = 0; k < NIX; ++k)
             if (has_next && tid + k * NTHR < 5 * TE) ti_next[tid + k * NTHR] = r_next[k];
@@ -455,6 +479,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
         layernorm_act<NTO, NW, ACT_O>(acc2, a.lnw[LO] + wave * NTO * 16 + 4 * g, a.lnb[LO] + wave * NTO * 16 + 4 * g, a.act[LO],
                                       a.eps, red, wave, ei, g);
         // (the barrier inside: every wave is past the hidden planes, the next tile's indices are visible)
+        HGNN_STAMP(7);
         if (has_next && npass > 0) {
             pissue(0, ti_next);
             if (npass > 1) pissue(1, ti_next);
@@ -470,6 +495,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
                 *(f32x4*)(a.out + off[j] + t * 16) = v;
             }
         }
+        HGNN_STAMP(8);
     }
 }
 
