@@ -380,3 +380,81 @@ def test_dispatch_options_are_context_local():
         assert torch.equal(a, c) and not torch.equal(a, b) and float((a - b).abs().max()) < 1e-4
     finally:
         fused.set_fp32_split3(old)
+
+
+@pytest.mark.parametrize("nseg,M,hidden_act,out_act,skip", [
+    (3, 32768, "GELU", "Tanh", True),      # the edge update: two projected node segments + the edge rows
+    (3, 33001, "GELU", "Tanh", True),      # ragged last tile (33001 = 257 tiles of 128 + 105 rows)
+    (2, 40000, "GELU", "GELU", True),      # the node update's shape
+    (1, 32900, "Tanh", "Tanh", True),      # one direct segment: no projected rows at all
+    (3, 35000, "ReLU", "ReLU", True),      # activations without a compiled pair: the run-time switch
+    (3, 36000, "GELU", "Tanh", False),     # no skip connection
+])
+def test_split3_rows128_kernel_variants_vs_fp64_and_vs_the_64_row_kernel(split3, nseg, M, hidden_act, out_act, skip):
+    """K -> 512 -> 256 at M >= 32,768 runs the 128-row-tile kernel (k_mlp_f32_split3_r128); below, or with
+    hgnn_set_option("mlp_split3_rows128", 0), the 64-row one.  Same arithmetic (bf16 split-3 products, fp32 accumulation and
+    LayerNorm), different summation order in the row statistics: both within 2e-5 of fp64, and of each other within 2e-6."""
+    from hierarchicalgnn_amd import _lib, make_mlp
+    L = 256
+    torch.manual_seed(nseg * 1000 + M)
+    net = make_mlp(nseg * L, 2 * L, L, 2, layer_norm=True, output_activation=out_act, hidden_activation=hidden_act).cuda()
+    for p in net.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.2 * torch.randn_like(p))
+    n_tab = M // 17
+    table = torch.randn(n_tab, L, device="cuda")
+    i0 = torch.randint(0, n_tab, (M,), device="cuda")
+    i1 = torch.sort(torch.randint(0, n_tab, (M,), device="cuda")).values
+    direct = torch.randn(M, L, device="cuda")
+    segs = [(table, i0), (table, i1), (direct, None)][3 - nseg:]
+    sk = direct if skip else None
+    lib = _lib.load()
+    with torch.no_grad():
+        assert split3.supported(net, segs, sk)
+        out128 = split3.fused_concat_mlp(net, segs, sk)
+        try:
+            _lib.check(lib.hgnn_set_option(b"mlp_split3_rows128", 0))
+            out64 = split3.fused_concat_mlp(net, segs, sk)
+        finally:
+            _lib.check(lib.hgnn_set_option(b"mlp_split3_rows128", 1))
+        x = torch.cat([t.double() if i is None else t.double()[i] for t, i in segs], dim=1)
+        ref = net.double()(x) + (direct.double() if skip else 0)
+        net.float()
+    scale = float(ref.abs().max())
+    # without the skip rows the output is the bare tanh (|out| <= 1, scale 1 instead of ~5): the same absolute error is a
+    # larger fraction of it
+    bar = 2e-5 if skip else 5e-5
+    assert float((out128.double() - ref).abs().max()) / scale <= bar
+    assert float((out64.double() - ref).abs().max()) / scale <= bar
+    assert float((out128 - out64).abs().max()) / scale <= 2e-6
+    assert not torch.equal(out128[-1], torch.zeros_like(out128[-1]))
+
+
+def test_split3_rows128_training_forward_dumps_match_the_64_row_kernel(split3):
+    """save_pre (the pre-LayerNorm dumps the backward recomputes from) out of the 128-row kernel: gradients of an edge-update
+    MLP at M = 33,000 against fp64 autograd."""
+    from hierarchicalgnn_amd import make_mlp
+    L, M = 256, 33000
+    torch.manual_seed(5)
+    net = make_mlp(3 * L, 2 * L, L, 2, layer_norm=True, output_activation="Tanh", hidden_activation="GELU").cuda()
+    n_tab = 2000
+    table = torch.randn(n_tab, L, device="cuda", requires_grad=True)
+    i0 = torch.randint(0, n_tab, (M,), device="cuda")
+    i1 = torch.sort(torch.randint(0, n_tab, (M,), device="cuda")).values
+    direct = torch.randn(M, L, device="cuda", requires_grad=True)
+    gout = torch.randn(M, L, device="cuda")
+    segs = [(table, i0), (table, i1), (direct, None)]
+    assert split3.supported_train(net, segs, direct)
+    out = split3.fused_concat_mlp_train(net, segs, direct)
+    out.backward(gout)
+    got = [table.grad.clone(), direct.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+    table.grad = direct.grad = None
+    net.zero_grad()
+    net64 = net.double()
+    t64, d64 = table.detach().double().requires_grad_(), direct.detach().double().requires_grad_()
+    ref = net64(torch.cat([t64[i0], t64[i1], d64], dim=1)) + d64
+    ref.backward(gout.double())
+    want = [t64.grad, d64.grad] + [p.grad for p in net64.parameters()]
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+    for g, w in zip(got, want):
+        assert float((g.double() - w).abs().max() / w.abs().max()) <= 5e-5

@@ -34,7 +34,8 @@ static unsigned short bf16_of(float x) {
     return (unsigned short)((u + 0x7fff + ((u >> 16) & 1)) >> 16);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool wide = argc > 1 && !strcmp(argv[1], "r128");   // argv[1]: "r128" | "r64"; argv[2]: start stagger in cycles per slot   // the 128-row kernel (11 stamps, 4 waves)
     using namespace hgnn;
     const long long N = 120000, M = 2000000;
     const int L = 256, H = 512;
@@ -74,9 +75,10 @@ int main() {
     CK(hipMemcpy(d_g1, g1.data(), M * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_zero, par.data(), H * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_one, one.data(), H * 4, hipMemcpyHostToDevice));
-    const long long n_tiles = (M + 63) / 64;
+    const int TEH = wide ? 128 : 64, NWH = 8, NSH = wide ? 12 : 9, NPH = wide ? 10 : 8;
+    const long long n_tiles = (M + TEH - 1) / TEH;
     unsigned long long* d_st;
-    const size_t n_st = (size_t)n_tiles * 8 * 9;
+    const size_t n_st = (size_t)n_tiles * NWH * NSH;
     CK(hipMalloc(&d_st, n_st * 8));
     CK(hipMemset(d_st, 0, n_st * 8));
     f3::Args a;
@@ -105,15 +107,16 @@ int main() {
     a.n_pre = 2;
     a.stamps = nullptr;
     a.stamp_tiles = 0;
+    a.stagger = argc > 2 ? atoi(argv[2]) : 0;
     for (int i = 0; i < 3; ++i)
-        if (f3::launch<8, 4, 2, 2>(a, 0) != HGNN_OK) return 1;   // warm-up, clocks settle
+        if ((wide ? f3::r128::launch_r128(a, 0) : f3::launch<8, 4, 2, 2>(a, 0)) != HGNN_OK) return 1;   // warm-up, clocks settle
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0));
     for (int i = 0; i < 5; ++i)
-        if (f3::launch<8, 4, 2, 2>(a, 0) != HGNN_OK) return 1;
+        if ((wide ? f3::r128::launch_r128(a, 0) : f3::launch<8, 4, 2, 2>(a, 0)) != HGNN_OK) return 1;
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms_plain = 0;
@@ -121,7 +124,7 @@ int main() {
     a.stamps = d_st;
     a.stamp_tiles = n_tiles;
     CK(hipEventRecord(e0));
-    if (f3::launch<8, 4, 2, 2>(a, 0) != HGNN_OK) return 1;
+    if ((wide ? f3::r128::launch_r128(a, 0) : f3::launch<8, 4, 2, 2>(a, 0)) != HGNN_OK) return 1;
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms_st = 0;
@@ -129,29 +132,34 @@ int main() {
     std::vector<unsigned long long> st(n_st);
     CK(hipMemcpy(st.data(), d_st, n_st * 8, hipMemcpyDeviceToHost));
     // per phase: cycles from the tile's earliest stamp k to its earliest / latest stamp k+1 over the 8 waves; medians over tiles
-    const char* names[8] = {"projected_rows_P_phase", "first_panel_store_and_barrier", "layer1_gemm", "layer1_layernorm_gelu",
-                            "hidden_planes_write_and_barrier", "output_gemm", "output_layernorm_tanh", "skip_add_and_stores"};
-    printf("{\n \"kernel\": \"k_mlp_f32_split3<8,4,2,2,GELU,TANH> with HGNN_SPLIT3_STAMPS\", \"M\": %lld, \"tiles\": %lld,\n", M, n_tiles);
-    printf(" \"ms_per_launch_without_stamp_writes\": %.4f, \"ms_with_stamp_writes\": %.4f,\n", ms_plain / 5, ms_st);
+    const char* names8[8] = {"projected_rows_P_phase", "first_panel_store_and_barrier", "layer1_gemm", "layer1_layernorm_gelu",
+                             "hidden_planes_write_and_barrier", "output_gemm", "output_layernorm_tanh", "skip_add_and_stores"};
+    const char* names10[10] = {"projected_rows_P_phase", "panel_pair_load_store_barrier", "layer1_gemm", "layer1_stats",
+                               "half0_activate_write_barrier", "output_gemm_half0", "half1_activate_write_barriers",
+                               "output_gemm_half1", "output_stats", "activate_skip_store"};
+    const char** names = wide ? names10 : names8;
+    printf("{\n \"kernel\": \"%s with HGNN_SPLIT3_STAMPS\", \"M\": %lld, \"tiles\": %lld,\n",
+           wide ? "k_mlp_f32_split3_r128<GELU,TANH>" : "k_mlp_f32_split3<8,4,2,2,GELU,TANH>", M, n_tiles);
+    printf(" \"stagger_cycles_per_slot\": %d, \"ms_per_launch_without_stamp_writes\": %.4f, \"ms_with_stamp_writes\": %.4f,\n", a.stagger, ms_plain / 5, ms_st);
     std::vector<double> tile_total;
-    std::vector<std::vector<double>> ph(8), skew(9);
+    std::vector<std::vector<double>> ph(NPH), skew(NPH + 1);
     for (long long t = 0; t < n_tiles; ++t) {
-        unsigned long long lo[9], hi[9];
+        unsigned long long lo[12], hi[12];
         bool ok = true;
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k <= NPH; ++k) {
             lo[k] = ~0ull;
             hi[k] = 0;
-            for (int w = 0; w < 8; ++w) {
-                const unsigned long long v = st[((size_t)t * 8 + w) * 9 + k];
+            for (int w = 0; w < NWH; ++w) {
+                const unsigned long long v = st[((size_t)t * NWH + w) * NSH + k];
                 if (v == 0) ok = false;
                 lo[k] = std::min(lo[k], v);
                 hi[k] = std::max(hi[k], v);
             }
         }
-        if (!ok || hi[8] < lo[0]) continue;
-        tile_total.push_back((double)(hi[8] - lo[0]));
-        for (int k = 0; k < 8; ++k) ph[k].push_back((double)(hi[k + 1]) - (double)(hi[k]));
-        for (int k = 0; k < 9; ++k) skew[k].push_back((double)(hi[k] - lo[k]));
+        if (!ok || hi[NPH] < lo[0]) continue;
+        tile_total.push_back((double)(hi[NPH] - lo[0]));
+        for (int k = 0; k < NPH; ++k) ph[k].push_back((double)(hi[k + 1]) - (double)(hi[k]));
+        for (int k = 0; k <= NPH; ++k) skew[k].push_back((double)(hi[k] - lo[k]));
     }
     auto med = [](std::vector<double>& v) {
         if (v.empty()) return 0.0;
@@ -160,9 +168,9 @@ int main() {
     };
     printf(" \"tiles_with_complete_stamps\": %zu, \"median_tile_cycles\": %.0f,\n", tile_total.size(), med(tile_total));
     printf(" \"median_phase_cycles_last_wave_to_last_wave\": {");
-    for (int k = 0; k < 8; ++k) printf("%s\"%s\": %.0f", k ? ", " : "", names[k], med(ph[k]));
+    for (int k = 0; k < NPH; ++k) printf("%s\"%s\": %.0f", k ? ", " : "", names[k], med(ph[k]));
     printf("},\n \"median_wave_skew_cycles_at_each_stamp\": [");
-    for (int k = 0; k < 9; ++k) printf("%s%.0f", k ? ", " : "", med(skew[k]));
+    for (int k = 0; k <= NPH; ++k) printf("%s%.0f", k ? ", " : "", med(skew[k]));
     printf("],\n \"ideal\": {\"mfma_cycles_per_wave_layer1\": 6144, \"mfma_cycles_per_wave_output\": 6144, \"note\": \"16 cycles x 384 MFMAs per GEMM and wave; two waves share a SIMD\"}\n}\n");
     return 0;
 }
