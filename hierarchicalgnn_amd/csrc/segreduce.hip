@@ -25,7 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern int g_opt_mlp_ablate;
 extern int g_opt_mlp_split_variant;
-namespace f3 { extern int g_opt_split3_rows128; extern int g_opt_split3_stagger; }
+namespace f3 { extern int g_opt_split3_rows128; extern int g_opt_split3_one_wg; }
 
 static int g_opt_nt_loads = 1;   // non-temporal loads for once-read source rows
 static int g_opt_nt_stores = 0;  // non-temporal stores for gather output
@@ -479,7 +479,7 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 31;
     else if (!strcmp(name, "mlp_split_variant")) g_opt_mlp_split_variant = value;
     else if (!strcmp(name, "mlp_split3_rows128")) f3::g_opt_split3_rows128 = value;
-    else if (!strcmp(name, "mlp_split3_stagger")) f3::g_opt_split3_stagger = value;
+    else if (!strcmp(name, "mlp_split3_one_wg")) f3::g_opt_split3_one_wg = value;
     else {
         set_error("hgnn_set_option: unknown option '%s'", name);
         return HGNN_ERR_INVALID_ARG;

@@ -35,7 +35,8 @@ static unsigned short bf16_of(float x) {
 }
 
 int main(int argc, char** argv) {
-    const bool wide = argc > 1 && !strcmp(argv[1], "r128");   // argv[1]: "r128" | "r64"; argv[2]: start stagger in cycles per slot   // the 128-row kernel (11 stamps, 4 waves)
+    const bool x2 = argc > 1 && !strcmp(argv[1], "r64x2");   // the K-half kernel on 64-row tiles, 4 waves, two workgroups per CU
+    const bool wide = x2 || (argc > 1 && !strcmp(argv[1], "r128"));   // argv[1]: "r128" | "r64"; argv[2]: start stagger in cycles per slot   // the 128-row kernel (11 stamps, 4 waves)
     using namespace hgnn;
     const long long N = 120000, M = 2000000;
     const int L = 256, H = 512;
@@ -75,7 +76,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_g1, g1.data(), M * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_zero, par.data(), H * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_one, one.data(), H * 4, hipMemcpyHostToDevice));
-    const int TEH = wide ? 128 : 64, NWH = 8, NSH = wide ? 12 : 9, NPH = wide ? 10 : 8;
+    const int TEH = wide && !x2 ? 128 : 64, NWH = x2 ? 4 : 8, NSH = wide ? 12 : 9, NPH = wide ? 10 : 8;
     const long long n_tiles = (M + TEH - 1) / TEH;
     unsigned long long* d_st;
     const size_t n_st = (size_t)n_tiles * NWH * NSH;
@@ -109,14 +110,14 @@ int main(int argc, char** argv) {
     a.stamp_tiles = 0;
     a.stagger = argc > 2 ? atoi(argv[2]) : 0;
     for (int i = 0; i < 3; ++i)
-        if ((wide ? f3::r128::launch_r128(a, 0) : f3::launch<8, 4, 2, 2>(a, 0)) != HGNN_OK) return 1;   // warm-up, clocks settle
+        if ((x2 ? f3::r64x2::launch_tile(a, 0) : wide ? f3::r128::launch_tile(a, 0) : f3::launch<8, 4, 2, 2>(a, 0)) != HGNN_OK) return 1;   // warm-up, clocks settle
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0));
     for (int i = 0; i < 5; ++i)
-        if ((wide ? f3::r128::launch_r128(a, 0) : f3::launch<8, 4, 2, 2>(a, 0)) != HGNN_OK) return 1;
+        if ((x2 ? f3::r64x2::launch_tile(a, 0) : wide ? f3::r128::launch_tile(a, 0) : f3::launch<8, 4, 2, 2>(a, 0)) != HGNN_OK) return 1;
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms_plain = 0;
@@ -124,7 +125,7 @@ int main(int argc, char** argv) {
     a.stamps = d_st;
     a.stamp_tiles = n_tiles;
     CK(hipEventRecord(e0));
-    if ((wide ? f3::r128::launch_r128(a, 0) : f3::launch<8, 4, 2, 2>(a, 0)) != HGNN_OK) return 1;
+    if ((x2 ? f3::r64x2::launch_tile(a, 0) : wide ? f3::r128::launch_tile(a, 0) : f3::launch<8, 4, 2, 2>(a, 0)) != HGNN_OK) return 1;
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms_st = 0;
@@ -139,7 +140,7 @@ int main(int argc, char** argv) {
                                "output_gemm_half1", "output_stats", "activate_skip_store"};
     const char** names = wide ? names10 : names8;
     printf("{\n \"kernel\": \"%s with HGNN_SPLIT3_STAMPS\", \"M\": %lld, \"tiles\": %lld,\n",
-           wide ? "k_mlp_f32_split3_r128<GELU,TANH>" : "k_mlp_f32_split3<8,4,2,2,GELU,TANH>", M, n_tiles);
+           x2 ? "r64x2::k_mlp_f32_split3_khalf<GELU,TANH>" : wide ? "r128::k_mlp_f32_split3_khalf<GELU,TANH>" : "k_mlp_f32_split3<8,4,2,2,GELU,TANH>", M, n_tiles);
     printf(" \"stagger_cycles_per_slot\": %d, \"ms_per_launch_without_stamp_writes\": %.4f, \"ms_with_stamp_writes\": %.4f,\n", a.stagger, ms_plain / 5, ms_st);
     std::vector<double> tile_total;
     std::vector<std::vector<double>> ph(NPH), skew(NPH + 1);
