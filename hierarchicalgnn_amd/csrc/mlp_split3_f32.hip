@@ -524,7 +524,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_mlp_f32_split3(con
 //     then the second half, whose pre-activation accumulators simply stay in registers meanwhile;
 //   * both 128-wide k-panels of the (pre-projected) first layer are resident at once: layer 1 is one uninterrupted
 //     8-chunk stream per panel pair.
-// Same arithmetic, same weight streams, same descriptor as the 64-row kernel; selected by the host for M >= 32,768.
+// Same arithmetic, same weight streams, same descriptor as the 64-row kernel; selected by the host for M >= 65,536 (at 40k rows its 313 tiles quantise worse over 256 CUs than 625 64-row tiles: 0.228 vs 0.210 ms).
 #ifdef HGNN_SPLIT3_STAMPS
 #define HGNN_STAMPW(k)                                                                                             \
     do {                                                                                                           \
@@ -649,7 +649,7 @@ static int launch_linear(const float* x, int K, const unsigned short* W0, const 
 }
 
 int g_opt_split3_one_wg = 0;    // hgnn_set_option("mlp_split3_one_wg"): DIAGNOSTIC, one persistent workgroup per CU where two fit
-int g_opt_split3_rows128 = 1;   // hgnn_set_option("mlp_split3_rows128"): 1 (default) the 128-row kernel for K -> 512 -> 256 at M >= 32,768
+int g_opt_split3_rows128 = 1;   // hgnn_set_option("mlp_split3_rows128"): 1 (default) the 128-row kernel for K -> 512 -> 256 at M >= 65,536 (two tiles per CU)
 static int g_cus = 0;
 
 template <int NW, int NTH, int NTO, int NL, int ACT_H, int ACT_O>
@@ -776,8 +776,8 @@ extern "C" int hgnn_mlp_forward_f32_split3(const hgnn_mlp_desc* d, float* out, h
         return o == 512 ? f3::launch<8, 4, 4, 2>(a, stream) : f3::launch<4, 4, 4, 2>(a, stream);
     // latent 128: 4 waves (two 74-KiB workgroups per CU; 8 waves x 1/8 of 256 features left each wave 192 MFMAs per
     // tile against the tile's fixed costs)
-    if (d->n_layers == 2 && o == 256 && f3::g_opt_split3_rows128 == 1 && d->M >= 32768) return f3::r128::launch_tile(a, stream);
-    if (d->n_layers == 2 && o == 256 && f3::g_opt_split3_rows128 == 2 && d->M >= 32768) return f3::r64x2::launch_tile(a, stream);
+    if (d->n_layers == 2 && o == 256 && f3::g_opt_split3_rows128 == 1 && d->M >= 65536) return f3::r128::launch_tile(a, stream);
+    if (d->n_layers == 2 && o == 256 && f3::g_opt_split3_rows128 == 2 && d->M >= 65536) return f3::r64x2::launch_tile(a, stream);
     if (d->n_layers == 2) return o == 256 ? f3::launch<8, 4, 2, 2>(a, stream) : f3::launch<4, 4, 2, 2>(a, stream);
     return o == 256 ? f3::launch<8, 4, 2, 3>(a, stream) : f3::launch<4, 4, 2, 3>(a, stream);
 }

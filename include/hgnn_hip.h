@@ -113,7 +113,7 @@ int hgnn_sizeof_mlp_desc(void);
  *                  DMA, 4 skip barriers (tools/tune_mlp.py); feature-split bf16 kernel: 1 weights from chunk 0 only,
  *                  2 skip LayerNorm/act, 4 load only the first input panel, 8 skip the per-panel barriers, 16 LDS
  *                  operand reads from chunk 0 only (tools/tune_mlp_split.py)
- *   "mlp_split3_rows128" tile shape of hgnn_mlp_forward_f32_split3 for K -> 512 -> 256 at M >= 32,768: 1 (default)
+ *   "mlp_split3_rows128" tile shape of hgnn_mlp_forward_f32_split3 for K -> 512 -> 256 at M >= 65,536: 1 (default)
  *                  128-row tiles, 8 waves, hidden rows consumed in two K-halves; 0 the 64-row kernel that serves every
  *                  other shape; 2 EXPERIMENTAL 64-row tiles, 4 waves, two workgroups per CU -- fastest, but one of two
  *                  equivalent builds returned wrong elements, cause not found: never a default

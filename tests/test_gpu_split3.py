@@ -383,15 +383,15 @@ def test_dispatch_options_are_context_local():
 
 
 @pytest.mark.parametrize("nseg,M,hidden_act,out_act,skip", [
-    (3, 32768, "GELU", "Tanh", True),      # the edge update: two projected node segments + the edge rows
-    (3, 33001, "GELU", "Tanh", True),      # ragged last tile (33001 = 257 tiles of 128 + 105 rows)
-    (2, 40000, "GELU", "GELU", True),      # the node update's shape
-    (1, 32900, "Tanh", "Tanh", True),      # one direct segment: no projected rows at all
-    (3, 35000, "ReLU", "ReLU", True),      # activations without a compiled pair: the run-time switch
-    (3, 36000, "GELU", "Tanh", False),     # no skip connection
+    (3, 65536, "GELU", "Tanh", True),      # the edge update: two projected node segments + the edge rows
+    (3, 66001, "GELU", "Tanh", True),      # ragged last tile (66001 = 515 tiles of 128 + 81 rows)
+    (2, 70000, "GELU", "GELU", True),      # the node update's shape
+    (1, 65900, "Tanh", "Tanh", True),      # one direct segment: no projected rows at all
+    (3, 68000, "ReLU", "ReLU", True),      # activations without a compiled pair: the run-time switch
+    (3, 67000, "GELU", "Tanh", False),     # no skip connection
 ])
 def test_split3_rows128_kernel_variants_vs_fp64_and_vs_the_64_row_kernel(split3, nseg, M, hidden_act, out_act, skip):
-    """K -> 512 -> 256 at M >= 32,768 runs the 128-row-tile kernel (k_mlp_f32_split3_r128); below, or with
+    """K -> 512 -> 256 at M >= 65,536 runs the 128-row-tile kernel (r128::k_mlp_f32_split3_khalf); below, or with
     hgnn_set_option("mlp_split3_rows128", 0), the 64-row one.  Same arithmetic (bf16 split-3 products, fp32 accumulation and
     LayerNorm), different summation order in the row statistics: both within 2e-5 of fp64, and within 2e-5 (absolute) of
     each other."""
@@ -433,9 +433,9 @@ def test_split3_rows128_kernel_variants_vs_fp64_and_vs_the_64_row_kernel(split3,
 
 def test_split3_rows128_training_forward_dumps_match_the_64_row_kernel(split3):
     """save_pre (the pre-LayerNorm dumps the backward recomputes from) out of the 128-row kernel: gradients of an edge-update
-    MLP at M = 33,000 against fp64 autograd."""
+    MLP at M = 66,000 against fp64 autograd."""
     from hierarchicalgnn_amd import make_mlp
-    L, M = 256, 33000
+    L, M = 256, 66000
     torch.manual_seed(5)
     net = make_mlp(3 * L, 2 * L, L, 2, layer_norm=True, output_activation="Tanh", hidden_activation="GELU").cuda()
     n_tab = 2000

@@ -1,4 +1,5 @@
 // DIAGNOSTIC build of hgnn_mlp_forward_f32_split3 (edge-update shape: node segments pre-projected, K1 = 256 -> 512 -> 256,
+// tile shape argv[1] in {r64, r128, r64x2}; argv[2]: optional start stagger in cycles per workgroup slot;
 // M = 2M rows) with shader-clock stamps at the phase boundaries of every tile (see HGNN_STAMP in mlp_split3_f32.hip).
 // Random data; the product library contains no stamp.  Build and run on the GPU box:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DHGNN_SPLIT3_STAMPS tools/split3_stamps.hip -o tools/split3_stamps
@@ -172,6 +173,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < NPH; ++k) printf("%s\"%s\": %.0f", k ? ", " : "", names[k], med(ph[k]));
     printf("},\n \"median_wave_skew_cycles_at_each_stamp\": [");
     for (int k = 0; k <= NPH; ++k) printf("%s%.0f", k ? ", " : "", med(skew[k]));
-    printf("],\n \"ideal\": {\"mfma_cycles_per_wave_layer1\": 6144, \"mfma_cycles_per_wave_output\": 6144, \"note\": \"16 cycles x 384 MFMAs per GEMM and wave; two waves share a SIMD\"}\n}\n");
+    const int mf = (wide && !x2) ? 768 : (x2 ? 768 : 384);   // MFMAs per GEMM and wave
+    printf("],\n \"ideal\": {\"mfma_cycles_per_wave_layer1\": %d, \"mfma_cycles_per_wave_output\": %d, \"note\": \"16 cycles x %d MFMAs per GEMM and wave; two waves share a SIMD\"}\n}\n", 16 * mf, 16 * mf, mf);
     return 0;
 }
