@@ -490,3 +490,41 @@ def test_split3_two_workgroups_per_cu_are_bitwise_the_one_workgroup_result(split
             _lib.check(lib.hgnn_set_option(b"mlp_split3_one_wg", 0))
     for t in two:
         assert torch.equal(t, one)
+
+
+@pytest.mark.parametrize("dtype,L,layers,M,split", [
+    ("f32", 128, 2, 200_003, True),     # latent-128 edge update, two workgroups per CU
+    ("f32", 128, 3, 120_000, True),     # latent-128 node update (three layers)
+    ("f32", 256, 2, 200_003, True),     # latent-256 edge update on 128-row tiles
+    ("f32", 256, 2, 40_000, True),      # ... on 64-row tiles (below two tiles per CU)
+    ("f32", 256, 2, 100_000, False),    # exact fp32 MFMA kernel
+    ("bf16", 256, 2, 200_003, False),   # bf16 rows, feature-split kernel
+    ("bf16", 512, 2, 100_000, False),
+])
+def test_mlp_kernels_are_bitwise_repeatable(dtype, L, layers, M, split):
+    """No atomics, no cross-workgroup reduction, fixed summation orders: every fused MLP kernel must return the SAME bits on
+    every run.  (The experimental two-workgroup tile of DESIGN.md section 3 (8) fails exactly this; a data race or a
+    scheduling-dependent hazard in a shipped kernel would show here as run-to-run differences.)"""
+    from hierarchicalgnn_amd import fused, make_mlp
+    old = fused._fp32_split3
+    fused.set_fp32_split3(split)
+    try:
+        torch.manual_seed(L + layers + M)
+        out_act = "Tanh" if layers == 2 else "GELU"
+        net = make_mlp(3 * L, 2 * L, L, layers, layer_norm=True, output_activation=out_act, hidden_activation="GELU").cuda()
+        n_tab = M // 17
+        table = torch.randn(n_tab, L, device="cuda")
+        direct = torch.randn(M, L, device="cuda")
+        if dtype == "bf16":
+            table, direct = table.bfloat16(), direct.bfloat16()
+        i0 = torch.randint(0, n_tab, (M,), device="cuda")
+        i1 = torch.sort(torch.randint(0, n_tab, (M,), device="cuda")).values
+        segs = [(table, i0), (table, i1), (direct, None)]
+        with torch.no_grad():
+            assert fused.supported(net, segs, direct)
+            first = fused.fused_concat_mlp(net, segs, direct)
+            for _ in range(4):
+                assert torch.equal(fused.fused_concat_mlp(net, segs, direct), first)
+        assert bool(torch.isfinite(first.float()).all())
+    finally:
+        fused.set_fp32_split3(old)
