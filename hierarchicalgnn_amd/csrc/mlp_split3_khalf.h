@@ -381,11 +381,9 @@ __global__ __launch_bounds__(WNW * 64, 2) void k_mlp_f32_split3_khalf(const Args
         constexpr int LO = 1;
         const u16x8* wpo = (const u16x8*)a.W[LO] + (size_t)(wave * WNTO) * 64 + lane;
         const char* hlane = smem + ei * WHRS + (g << 4);
-        const float* lnw1 = a.lnw[0] + wave * WNTH * 16 + 4 * g;
-        const float* lnb1 = a.lnb[0] + wave * WNTH * 16 + 4 * g;
         int r_next[NIX];
         // half 0: tiles 0-1 of every wave = hidden features 64 w + [0, 32) = stream chunk 2 w
-        act_write_half<0, ACT_H>(acc1, lnw1, lnb1, a.act[0], rstd, shift, smem + ei * WHRS + wave * (WNTH * 16) + (g << 3));
+        act_write_half<0, ACT_H>(acc1, a.lnw[0] + wave * WNTH * 16 + 4 * g, a.lnb[0] + wave * WNTH * 16 + 4 * g, a.act[0], rstd, shift, smem + ei * WHRS + wave * (WNTH * 16) + (g << 3));
         __syncthreads();
         HGNN_STAMPW(5);
         f32x4 acc2[WNTO][WNJ];
@@ -404,7 +402,17 @@ __global__ __launch_bounds__(WNW * 64, 2) void k_mlp_f32_split3_khalf(const Args
         for (int k = 0; k < NIX; ++k) r_next[k] = has_next ? fetch_index(tile + gridDim.x, k) : 0;
         HGNN_STAMPW(6);
         __syncthreads();                 // every wave is done reading half 0
-        act_write_half<WNTH / 2, ACT_H>(acc1, lnw1, lnb1, a.act[0], rstd, shift, smem + ei * WHRS + wave * (WNTH * 16) + (g << 3));
+        // the row statistics are re-read from LDS (still there: the next statistics pass comes after the output GEMM) instead
+        // of living in 16 registers across the first half's GEMM -- hipcc spilled them (0.5 GB of scratch writes per launch)
+        refresh();
+        float rstd_b[WNJ], shift_b[WNJ];
+#pragma unroll
+        for (int j = 0; j < WNJ; ++j) {
+            const f32x2 rs = *(const f32x2*)(red + (j * 16 + ei) * 2);
+            rstd_b[j] = rs.x;
+            shift_b[j] = rs.y;
+        }
+        act_write_half<WNTH / 2, ACT_H>(acc1, a.lnw[0] + wave * WNTH * 16 + 4 * g, a.lnb[0] + wave * WNTH * 16 + 4 * g, a.act[0], rstd_b, shift_b, smem + ei * WHRS + wave * (WNTH * 16) + (g << 3));
         __syncthreads();
         HGNN_STAMPW(7);
         gemm3w<WNTO, WHRS>(acc2, wpo, [](int s) { return 2 * ((s / WCW) * 2 * WCW + WCW + s % WCW); }, hlane, hlane + WPLB, 8);
