@@ -133,7 +133,10 @@ def launch(argv, world: int, timeout_s: float = 3000.0, python: str | None = Non
                 p.kill()
                 p.wait()
     out0.seek(0)
-    sys.stdout.write(out0.read())
+    for line in out0.read().splitlines(keepends=True):
+        # stdout carries the ONE JSON line of rank 0; whatever a library printed there (gloo's "[Gloo] Rank 0 is connected
+        # ..." banner of the CPU rehearsal) goes to stderr
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
     sys.stdout.flush()
     out0.close()
     for p in procs:
