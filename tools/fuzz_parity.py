@@ -121,6 +121,35 @@ for case in range(n_cases):
     for k, (a, b) in enumerate(zip(got, want)):
         note("fused_mlp_f32_grads", rel(a, b), 2e-4, (L, layers, Mm, n_tab, k))
 
+    # ---------------- the 128-row tile of the split-bf16 fp32 MLP (K -> 512 -> 256 from 65,536 rows), every 8th case
+    if case % 8 == 0:
+        Lb, nseg_b = 256, ri(1, 3)
+        Mb = ri(65536, 90000)
+        nt = ri(50, 5000)
+        netb = make_mlp(nseg_b * Lb, 2 * Lb, Lb, 2, layer_norm=True, output_activation=["Tanh", "GELU", "ReLU"][ri(0, 2)],
+                        hidden_activation=["GELU", "Tanh"][ri(0, 1)]).cuda()
+        tb = torch.randn(nt, Lb, generator=g).cuda()
+        db = torch.randn(Mb, Lb, generator=g).cuda()
+        j0 = torch.randint(0, nt, (Mb,), generator=g).cuda()
+        j1 = torch.randint(0, nt, (Mb,), generator=g).cuda()
+        if ri(0, 1):
+            j1 = torch.sort(j1).values
+        segs_b = [(tb, j0), (tb, j1), (db, None)][3 - nseg_b:]
+        skip_b = db if ri(0, 3) else None
+        fused.set_fp32_split3(True)
+        try:
+            n_s3 = fused.stats.get("split3_calls", 0)
+            with torch.no_grad():
+                ob = mlp.concat_mlp(netb, segs_b, skip=skip_b)
+                xb = torch.cat([t.double() if i is None else t.double()[i] for t, i in segs_b], dim=1)
+                rb = netb.double()(xb) + (db.double() if skip_b is not None else 0)
+                netb.float()
+            assert fused.stats.get("split3_calls", 0) == n_s3 + 1
+        finally:
+            fused.set_fp32_split3(False)
+        err_b = float((ob.double() - rb).abs().max()) / max(float(rb.abs().max()), 1.0)
+        note("fused_mlp_f32_split3_rows128_vs_fp64", err_b, 5e-5, (nseg_b, Mb, nt, skip_b is not None))
+
     # ---------------- fused MLP, bf16
     if L >= 64:
         segs16 = [(tab.bfloat16(), i0), (tab.bfloat16(), i1), (direct.bfloat16(), None)]
