@@ -17,6 +17,7 @@
 // list): no atomics, every output row is written exactly once with 16-B
 // stores, and the summation order is fixed by the plan.
 #include "common.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace hgnn {
@@ -478,7 +479,15 @@ extern "C" int hgnn_set_option(const char* name, int value) {
     else if (!strcmp(name, "nt_stores")) g_opt_nt_stores = value;
     else if (!strcmp(name, "mlp_ablate")) g_opt_mlp_ablate = value & 31;
     else if (!strcmp(name, "mlp_split_variant")) g_opt_mlp_split_variant = value;
-    else if (!strcmp(name, "mlp_split3_rows128")) f3::g_opt_split3_rows128 = value;
+    else if (!strcmp(name, "mlp_split3_rows128")) {
+        // 2 = the two-workgroup tile that returned wrong elements in one of two equivalent builds:
+        // measurement tools only, behind an environment switch of its own
+        if (value < 0 || value > 2 || (value == 2 && getenv("HGNN_EXPERIMENTAL") == nullptr)) {
+            set_error("hgnn_set_option: mlp_split3_rows128 takes 0 or 1 (2 = experimental tile, needs HGNN_EXPERIMENTAL=1)");
+            return HGNN_ERR_INVALID_ARG;
+        }
+        f3::g_opt_split3_rows128 = value;
+    }
     else if (!strcmp(name, "mlp_split3_one_wg")) f3::g_opt_split3_one_wg = value;
     else {
         set_error("hgnn_set_option: unknown option '%s'", name);

@@ -116,7 +116,8 @@ int hgnn_sizeof_mlp_desc(void);
  *   "mlp_split3_rows128" tile shape of hgnn_mlp_forward_f32_split3 for K -> 512 -> 256 at M >= 65,536: 1 (default)
  *                  128-row tiles, 8 waves, hidden rows consumed in two K-halves; 0 the 64-row kernel that serves every
  *                  other shape; 2 EXPERIMENTAL 64-row tiles, 4 waves, two workgroups per CU -- fastest, but one of two
- *                  equivalent builds returned wrong elements, cause not found: never a default
+ *                  equivalent builds returned wrong elements, cause not found: never a default, and
+ *                  refused unless the environment variable HGNN_EXPERIMENTAL is set
  *   "mlp_split3_one_wg"  DIAGNOSTIC: 1 launches one persistent workgroup per CU where two fit (results must be
  *                  bitwise the same: tests/test_gpu_split3.py)
  * Any other name is an error (HGNN_ERR_INVALID_ARG). */

@@ -83,6 +83,11 @@ def test_unknown_option_is_an_error():
     lib = _lib.load()
     assert lib.hgnn_set_option(b"nt_loads", 1) == 0
     assert lib.hgnn_set_option(b"no_such_option", 1) != 0
+    # the experimental two-workgroup tile of the split3 MLP is refused without HGNN_EXPERIMENTAL (include/hgnn_hip.h)
+    if "HGNN_EXPERIMENTAL" not in os.environ:
+        assert lib.hgnn_set_option(b"mlp_split3_rows128", 2) != 0 and b"experimental" in lib.hgnn_last_error()
+    assert lib.hgnn_set_option(b"mlp_split3_rows128", 3) != 0
+    assert lib.hgnn_set_option(b"mlp_split3_rows128", 1) == 0
     # round-2 A/B variants that measured slower were removed with their options (include/hgnn_hip.h)
     for gone in (b"seg_grouped", b"mlp_rows128", b"mlp_f32_waves", b"mlp_split_shape", b"seg_xcd"):
         assert lib.hgnn_set_option(gone, 1) != 0

@@ -8,6 +8,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("HGNN_EXPERIMENTAL", "1")   # option value 2 (the experimental two-workgroup tile) is refused without it
 import torch
 from hierarchicalgnn_amd import _lib, fused, make_mlp, mlp, synth
 

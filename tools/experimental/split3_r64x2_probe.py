@@ -6,6 +6,7 @@ and ~6 % more a wrong output element; with hgnn_set_option("mlp_split3_one_wg", 
 Usage: python tools/experimental/split3_r64x2_probe.py [label]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("HGNN_EXPERIMENTAL", "1")   # option value 2 (the experimental two-workgroup tile) is refused without it
 import torch
 from hierarchicalgnn_amd import _lib, fused, make_mlp
 lib = _lib.load()
